@@ -1,0 +1,68 @@
+"""Pin the oracle against vectors produced by the reference's own modules (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from canonswap_amd import synth
+from oracle import canonswap_ref as O
+
+BOUNDARIES = ("f_s", "f_can", "occ", "f_swap", "f_ref", "seg", "deformation", "occ2")
+
+
+def _inputs(g):
+    inp = synth.make_frame_inputs(int(g["n_frames"]), seed=int(g["frame_seed"]), size=int(g["size"]))
+    idv = torch.from_numpy(synth.make_identity(int(g["id_seed"])))
+    return [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")] + [idv]
+
+
+@pytest.mark.parametrize("name,debug", [("frame_128_b2.npz", True), ("frame_256_b1.npz", False)])
+def test_oracle_matches_reference_vectors(golden, state_dicts, name, debug):
+    g = golden(name)
+    r = O.swap_frame(state_dicts, *_inputs(g), debug=debug)
+    for k in BOUNDARIES:
+        v = r[k].numpy().reshape(-1)
+        ref = g[k + "_val"]
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(v[g[k + "_idx"]] - ref).max() <= 2e-4 * scale, k
+        assert abs(v.mean() - g[k + "_stats"][0]) <= 1e-4 * scale, k
+    # fp16 storage of the golden image bounds the achievable PSNR at ~75 dB
+    assert O.psnr(r["out"], torch.from_numpy(g["out_f16"].astype(np.float32))) > 70.0
+    if debug:
+        for k in ("rec_can", "swap_can"):
+            assert O.psnr(r[k], torch.from_numpy(g[k + "_f16"].astype(np.float32))) > 70.0
+
+
+def test_grid_sample_restatement():
+    r = np.random.Generator(np.random.PCG64(5))
+    x = torch.from_numpy(r.standard_normal((2, 4, 6, 9, 11)).astype(np.float32))
+    grid = torch.from_numpy(r.uniform(-1.3, 1.3, size=(2, 5, 7, 8, 3)).astype(np.float32))
+    a = torch.nn.functional.grid_sample(x, grid, align_corners=False)
+    b = O.grid_sample_3d_explicit(x, grid)
+    assert (a - b).abs().max() < 1e-5
+
+
+def test_camera_and_keypoint_transform(golden):
+    g = golden("unit_vectors.npz")
+    pyr = torch.from_numpy(g["pyr"])
+    rot = O.get_rotation_matrix(pyr[:, 0], pyr[:, 1], pyr[:, 2])
+    assert np.abs(rot.numpy() - g["rot"]).max() < 1e-6
+    assert np.abs(O.headpose_pred_to_degree(torch.from_numpy(g["bins"])).numpy() - g["deg"]).max() < 1e-4
+    info = dict(kp=torch.from_numpy(g["kp"]), exp=torch.from_numpy(g["exp"]), t=torch.from_numpy(g["t"]),
+                scale=torch.from_numpy(g["scale"]), pitch=pyr[:, 0:1], yaw=pyr[:, 1:2], roll=pyr[:, 2:3])
+    assert np.abs(O.transform_keypoint(info).numpy() - g["x_transformed"]).max() < 1e-5
+
+
+def test_parse_output_truncates():
+    x = torch.tensor([[[[0.0, 0.999, 1.0, 1.7, -0.2, 0.5]]]]).repeat(1, 3, 1, 1)
+    u8 = O.parse_output(x)
+    assert u8.dtype == np.uint8 and u8.shape == (1, 1, 6, 3)
+    assert u8[0, 0, :, 0].tolist() == [0, 254, 255, 255, 0, 127]   # 0.5*255 = 127.5 -> 127 (truncation)
+
+
+def test_prepare_source_roundtrip():
+    img = np.random.Generator(np.random.PCG64(1)).integers(0, 256, size=(8, 8, 3), dtype=np.uint8)
+    x = O.prepare_source(img)
+    assert x.shape == (1, 3, 8, 8) and x.dtype == torch.float32
+    assert np.array_equal(np.round(x.permute(0, 2, 3, 1).numpy()[0] * 255).astype(np.uint8), img)
+    v = O.prepare_videos([img, img])
+    assert v.shape == (2, 1, 3, 8, 8)
