@@ -1,0 +1,171 @@
+"""Drop-in counterpart of the reference's model wrapper ``can_swapper`` (src/can_swap_e2e.py:39-348).
+
+Same constructor argument, attribute names, method names and tensor signatures as the reference class, so
+``CanSwapPipeline`` (src/can_swap_pipeline_e2e.py:40,71-80,98,242-267) can use it unchanged; every tensor
+operation is executed by the gfx950 HIP engine (libcanonswap_hip.so) -- there is no PyTorch or CPU fallback.
+Stage attributes (``warping_module``, ``swap_module`` ...) are small callables bound to the C ABI.
+
+Outside the generator hot path ("next" rows): the motion extractor M (``get_kp_info``) and
+the ArcFace identity network (``getid``) are not part of this engine and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+
+import numpy as np
+import torch
+
+from .engine import Engine
+
+
+class _WarpingModule:
+    """WarpingNetwork surface used by the pipeline (warping_network.py:49-111)."""
+
+    def __init__(self, eng: Engine):
+        self._e = eng
+
+    def warp(self, feature_3d, kp_source, kp_driving):          # positional order as in the reference (:49)
+        return self._e.warp(feature_3d, kp_source, kp_driving)
+
+    def warp_out(self, out, occlusion_map=None):                # (:64)
+        return self._e.warp_out(out, occlusion_map)
+
+    def __call__(self, feature_3d, kp_driving, kp_source):      # forward(feature_3d, kp_driving, kp_source) (:83)
+        return self._e.warp_forward(feature_3d, kp_driving=kp_driving, kp_source=kp_source)
+
+    forward = __call__
+
+
+class _Callable:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __call__(self, *a, **k):
+        return self._fn(*a, **k)
+
+    forward = __call__
+
+
+class can_swapper(object):
+    """MI355X engine behind the reference's ``can_swapper`` interface."""
+
+    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8):
+        self.inference_cfg = inference_cfg
+        self.device_id = getattr(inference_cfg, "device_id", 0)
+        self.compile = False                      # torch.compile switch of the reference (:47,:74-77) has no meaning here
+        if getattr(inference_cfg, "flag_force_cpu", False):
+            raise RuntimeError("flag_force_cpu=True: this engine runs on an MI355X only (no CPU path)")
+        self.device = "cuda:" + str(self.device_id)
+        self.engine = Engine(self.device_id, max_batch=max_batch)
+        self.appearance_feature_extractor = _Callable(self.engine.extract_feature_3d)
+        self.warping_module = _WarpingModule(self.engine)
+        self.spade_generator = _Callable(lambda feature: self.engine.spade_decode(feature))
+        self.swap_module = _Callable(lambda f, source_id: self.engine.swap(f, source_id))
+        self.refine_module = _Callable(self.engine.refine)
+        self.motion_extractor = None
+        if state_dicts is not None:
+            self.load_state_dicts(state_dicts)
+        else:
+            self.load_cpk()
+
+    # ---- weights (can_swap_e2e.py:87-100)
+    def load_cpk(self, combined_weights_path: str = "pretrained_weights/combined_weights.pth"):
+        if os.path.exists(combined_weights_path):
+            combined = torch.load(combined_weights_path, map_location=torch.device("cpu"))
+            self.load_state_dicts(combined)
+
+    def load_state_dicts(self, combined: dict):
+        self.engine.load_state_dicts({k: combined[k] for k in
+                                      ("appearance_feature_extractor", "warping_module", "spade_generator", "transfer", "refine")})
+
+    # ---- small helpers kept for interface parity
+    def inference_ctx(self):
+        return contextlib.nullcontext()           # precision is fixed inside the engine (fp16 operands, fp32 accumulate)
+
+    def update_config(self, user_args):
+        for k, v in user_args.items():
+            if hasattr(self.inference_cfg, k):
+                setattr(self.inference_cfg, k, v)
+
+    def getid(self, img):
+        raise NotImplementedError("ArcFace identity extraction is outside the generator hot path; pass source_id (1x512)")
+
+    def get_kp_info(self, x, **kwargs):
+        raise NotImplementedError("motion extractor M is outside the generator hot path (SURVEY.md section 8f, N1)")
+
+    # ---- data preparation (:126-163)
+    def prepare_source(self, img: np.ndarray) -> torch.Tensor:
+        if img.shape[0] != 256 or img.shape[1] != 256:
+            raise ValueError("prepare_source expects the 256x256 crop produced by the cropper")
+        if img.ndim == 3:
+            x = img[np.newaxis].astype(np.float32) / 255.
+        elif img.ndim == 4:
+            x = img.astype(np.float32) / 255.
+        else:
+            raise ValueError(f'img ndim should be 3 or 4: {img.ndim}')
+        x = np.clip(x, 0, 1)
+        return torch.from_numpy(x).permute(0, 3, 1, 2).to(self.device)
+
+    def prepare_videos(self, imgs) -> torch.Tensor:
+        if isinstance(imgs, list):
+            _imgs = np.array(imgs)[..., np.newaxis]
+        elif isinstance(imgs, np.ndarray):
+            _imgs = imgs
+        else:
+            raise ValueError(f'imgs type error: {type(imgs)}')
+        y = np.clip(_imgs.astype(np.float32) / 255., 0, 1)
+        return torch.from_numpy(y).permute(0, 4, 3, 1, 2).to(self.device)
+
+    # ---- stages
+    def extract_feature_3d(self, x: torch.Tensor) -> torch.Tensor:                      # (:165-172)
+        return self.engine.extract_feature_3d(x)
+
+    def swap(self, feature_3d, source_id):                                               # (:109-111)
+        return self.engine.swap(feature_3d, source_id)
+
+    def transform_keypoint(self, kp_info: dict):                                         # (:228-256); 21x3 host-size math
+        kp = kp_info['kp']
+        pitch, yaw, roll = (headpose_pred_to_degree(kp_info[k]) for k in ('pitch', 'yaw', 'roll'))
+        bs = kp.shape[0]
+        num_kp = kp.shape[1] // 3 if kp.ndim == 2 else kp.shape[1]
+        rot_mat = get_rotation_matrix(pitch, yaw, roll)
+        kp_t = kp.view(bs, num_kp, 3) @ rot_mat + kp_info['exp'].view(bs, num_kp, 3)
+        kp_t = kp_t * kp_info['scale'][..., None]
+        kp_t[:, :, 0:2] += kp_info['t'][:, None, 0:2]
+        return kp_t
+
+    def warp_decode(self, feature_3d, kp_source, kp_driving) -> dict:                    # (:286-308)
+        ret = self.engine.warp_forward(feature_3d, kp_driving=kp_driving, kp_source=kp_source)
+        ret['out'] = self.engine.spade_decode(ret['out'])
+        return ret
+
+    def conv_decode(self, out, occlusion_map=None) -> torch.Tensor:                      # (:309-312)
+        return self.engine.spade_decode(self.engine.warp_out(out, occlusion_map))
+
+    def parse_output(self, out: torch.Tensor) -> np.ndarray:                             # (:314-322), packed on device
+        return self.engine.pack_u8(out).cpu().numpy()
+
+    # ---- addition: the whole loop body of can_swap_pipeline_e2e.py:242-263 for a batch of frames
+    def swap_frames(self, I_s, x_t, x_can, source_id, debug=False, want_u8=False):
+        return self.engine.swap_frames(I_s, x_t, x_can, source_id, want_f32=True, want_u8=want_u8, debug=debug)
+
+
+def headpose_pred_to_degree(pred):
+    """src/utils/camera.py:14-28."""
+    if pred.ndim > 1 and pred.shape[1] == 66:
+        idx = torch.arange(66, dtype=torch.float32, device=pred.device)
+        return torch.sum(torch.softmax(pred, dim=1) * idx, dim=1) * 3 - 97.5
+    return pred
+
+
+def get_rotation_matrix(pitch_, yaw_, roll_):
+    """src/utils/camera.py:31-73 (degrees in; returns (Rz Ry Rx)^T)."""
+    x, y, z = [(a / 180 * np.pi) for a in (pitch_, yaw_, roll_)]
+    x, y, z = [a.unsqueeze(1) if a.ndim == 1 else a for a in (x, y, z)]
+    bs = x.shape[0]
+    one, zero = torch.ones(bs, 1, device=x.device), torch.zeros(bs, 1, device=x.device)
+    rx = torch.cat([one, zero, zero, zero, torch.cos(x), -torch.sin(x), zero, torch.sin(x), torch.cos(x)], 1).reshape(bs, 3, 3)
+    ry = torch.cat([torch.cos(y), zero, torch.sin(y), zero, one, zero, -torch.sin(y), zero, torch.cos(y)], 1).reshape(bs, 3, 3)
+    rz = torch.cat([torch.cos(z), -torch.sin(z), zero, torch.sin(z), torch.cos(z), zero, zero, zero, one], 1).reshape(bs, 3, 3)
+    return (rz @ ry @ rx).permute(0, 2, 1)

@@ -1,0 +1,98 @@
+// Shared declarations for the CanonSwap gfx950 engine (kernels + host orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
+enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3 };
+// tile configurations of conv_igemm (pixels x channels per 256-thread workgroup)
+enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
+
+// A channels-last tensor view: element strides, channel stride is 1.
+struct TDesc {
+    void* p;
+    long sN, sD, sH, sW;
+};
+
+// Parameters of one implicit-GEMM convolution launch ("same" padding, stride 1, 1-3 spatial dims).
+// GEMM view: M = N*D*H*W output positions, N = Cout, K = taps * Cin.
+struct ConvParams {
+    // input activations, fp16, channels-last with arbitrary position strides
+    const half_t* in;
+    long in_sN, in_sD, in_sH, in_sW;
+    int N, D, H, W;     // output extents (the input is addressed at (h>>up_shift, w>>up_shift))
+    int Cin;            // valid input channels (multiple of 8)
+    int nchunks;        // ceil(Cin / 32)
+    int up_shift;       // nearest-neighbour up-sampling of the input folded into addressing
+    int KD, KH, KW, PD, PH, PW;
+    // packed weights [kstep][Cout_pad][32] fp16, kstep = ((chunk*KD+kd)*KH+kh)*KW+kw
+    const half_t* wgt;
+    int Cout_pad;       // packed rows (multiple of the channel tile)
+    int Cout;           // logical channels stored (multiple of 4)
+    // M-tile decomposition: tile = TN x TD x TH x TW positions (all powers of two)
+    int lgTW, lgTH, lgTD;
+    int nTW, nTH, nTD, nTN;
+    // ---- epilogue
+    const float* bias;      // [Cout] (BatchNorm / spectral norm already folded into wgt, bias)
+    const float* bias2;     // SPADE: beta bias
+    int act0;
+    float slope0;
+    TDesc res;              // residual (STD/TBLEND) or the tensor being modulated (SPADE)
+    int res_f32;
+    int res_shift;          // SPADE: x lives at (h>>res_shift, w>>res_shift)
+    const float* pixscale;  // per output position scalar: occlusion (STD) or blend mask (TBLEND)
+    int ps_stride;
+    TDesc out0;
+    int out0_f32;
+    const float* s2;        // second output: act1(v * s2[c] + t2[c]) as fp16 (next layer's pre-activation)
+    const float* t2;
+    int act1;
+    float slope1;
+    TDesc out1;
+    const float* stats;     // SPADE: [N][C][2] = (sum, sum of squares) of x over its H*W
+    float stat_cnt_inv;
+    float eps;
+};
+
+#define CS_CHECK_HIP(expr)                                                                  \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            cs_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+void cs_set_error(const char* fmt, ...);
+
+// ---- kernel launchers (conv_igemm.hip, kernels.hip); all asynchronous on `st`
+int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);
+
+int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);
+int launch_avgpool(const half_t* in, int N, int D, int H, int W, int C, TDesc out, hipStream_t st);
+int launch_dm_compress(const float* f, const float* w, const float* b, half_t* comp, int N, int D, int H, int W, hipStream_t st);
+int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, half_t* out, int out_stride, int N, int D,
+                     int H, int W, hipStream_t st);
+int launch_dm_softmax(const float* logits, int lstride, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
+                      int N, int D, int H, int W, hipStream_t st);
+int launch_dm_occlusion(const half_t* pred, int C, const half_t* w, float bias, float* occ, int N, int D, int H, int W,
+                        hipStream_t st);
+int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);
+int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, hipStream_t st);
+int launch_norm_act(const float* y, const float* stats, float cnt_inv, float eps, const float* gamma, const float* beta,
+                    const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
+                    int act2, float slope2, int N, long per_n, hipStream_t st);
+int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,
+                         int N, int C, int D, int H, int W, hipStream_t st);
+int launch_hwdc_to_ncdhw(const float* in, float* out, int N, int C, int D, int H, int W, hipStream_t st);
+int launch_nchw_to_nhwc16(const float* in, half_t* out, int N, int C, int HW, hipStream_t st);
+int launch_nhwc16_to_nchw(const half_t* in, float* out, int N, int C, int HW, hipStream_t st);
+int launch_t_style(const float* id, const float* fc, float* style, int nlayers, hipStream_t st);
+int launch_t_modulate(const float* wraw, const float* style, half_t* packed, int layer, hipStream_t st);
+int launch_pack_u8(const float* img, uint8_t* out, int N, int C, int H, int W, hipStream_t st);
+int launch_lrelu16(const half_t* in, half_t* out, long n, float slope, hipStream_t st);

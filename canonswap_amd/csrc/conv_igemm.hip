@@ -1,0 +1,288 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4): fp16 operands, fp32 accumulate on
+// v_mfma_f32_16x16x32_f16, channels-last activations with arbitrary position strides.
+//
+// Replaces every F.conv2d / F.conv3d / nn.Conv{2,3}d call site on the CanonSwap generator path
+// (util.py:80-344, appearance_feature_extractor.py:38-48, dense_motion.py:67-104,
+// warping_network.py:64-71, adaptive_modulate.py:128-193, spade_generator.py:41-59) with one kernel
+// family whose epilogue carries the surrounding element-wise work (folded eval-BatchNorm, activation,
+// residual add, occlusion multiply, pre-activation of the next layer, the T blend, SPADE modulation,
+// PixelShuffle + sigmoid).
+//
+// Work decomposition (64-lane wavefronts, 4 waves per workgroup):
+//   workgroup tile = BM output positions x BN output channels, K-step = 32 input channels of one tap
+//   LDS: activations [BM][32] and weights [BN][32] fp16, double buffered, 16-byte slots XOR-swizzled so
+//        that the ds_read_b128 lane groups of the MFMA operand fetch are bank-conflict free
+//   MFMA operand roles are swapped (A = weights -> rows = channels, B = activations -> columns =
+//   positions) so each lane ends up with 4 consecutive channels of one position: 8/16-byte stores.
+#include "common.h"
+
+__device__ __forceinline__ int swz_slot(int row, int seg)
+{
+    // f(q) = {0,2,3,1}[q], q = (row>>2)&3 : makes the four 16-lane groups of ds_read_b128 hit 16 distinct slots
+    return seg ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ void load4(const TDesc& t, int is_f32, long off, float v[4])
+{
+    if (is_f32) {
+        const float4 x = *(const float4*)((const float*)t.p + off);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+        const h4_t x = *(const h4_t*)((const half_t*)t.p + off);
+        v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+    }
+}
+
+__device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, const float v[4])
+{
+    if (is_f32) {
+        *(float4*)((float*)t.p + off) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        h4_t x;
+        x[0] = (half_t)v[0]; x[1] = (half_t)v[1]; x[2] = (half_t)v[2]; x[3] = (half_t)v[3];
+        *(h4_t*)((half_t*)t.p + off) = x;
+    }
+}
+
+template <int WPX, int WCH, int WVP, int WVC, int MODE>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
+{
+    constexpr int BM = WPX * 16 * WVP;
+    constexpr int BN = WCH * 16 * WVC;
+    constexpr int AR = BM / 64;                // activation rows staged per thread
+    constexpr int BL = (BN * 4 + 255) / 256;   // weight 16-byte pieces staged per thread
+    static_assert(WVP * WVC == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t* As = (half_t*)smem;          // [2][BM][32]
+    half_t* Bs = As + 2 * BM * 32;       // [2][BN][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wpx = wave % WVP, wch = wave / WVP;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    int t = blockIdx.x;
+    const int tw = t % p.nTW; t /= p.nTW;
+    const int th = t % p.nTH; t /= p.nTH;
+    const int td = t % p.nTD; t /= p.nTD;
+    const int tn = t;
+    const int n0 = blockIdx.y * BN;
+    const int lgS = p.lgTW + p.lgTH + p.lgTD;
+    const int mW = (1 << p.lgTW) - 1, mH = (1 << p.lgTH) - 1, mD = (1 << p.lgTD) - 1;
+
+    // position of the rows this thread stages
+    const int seg = tid & 3;
+    int rn[AR], rd[AR], rh[AR], rw[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int m = (tid >> 2) + 64 * i;
+        rw[i] = (tw << p.lgTW) + (m & mW); m >>= p.lgTW;
+        rh[i] = (th << p.lgTH) + (m & mH); m >>= p.lgTH;
+        rd[i] = (td << p.lgTD) + (m & mD); m >>= p.lgTD;
+        rn[i] = tn * (BM >> lgS) + m;
+    }
+
+    uint4 areg[AR], breg[BL];
+    auto gload = [&](int kd, int kh, int kw, int c0, int ks) {
+        const int dd = kd - p.PD, dh = kh - p.PH, dw = kw - p.PW;
+        const int cc = c0 + seg * 8;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int id = rd[i] + dd, ih = rh[i] + dh, iw = rw[i] + dw;
+            const bool ok = rn[i] < p.N && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H &&
+                            (unsigned)iw < (unsigned)p.W && cc < p.Cin;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const half_t* src = p.in + (long)rn[i] * p.in_sN + (long)id * p.in_sD +
+                                    (long)(ih >> p.up_shift) * p.in_sH + (long)(iw >> p.up_shift) * p.in_sW + cc;
+                v = *(const uint4*)src;
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < BN * 4)
+                breg[j] = *(const uint4*)(p.wgt + ((long)ks * p.Cout_pad + n0 + (idx >> 2)) * 32 + (idx & 3) * 8);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int row = (tid >> 2) + 64 * i;
+            *(uint4*)(As + buf * BM * 32 + row * 32 + swz_slot(row, seg) * 8) = areg[i];
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < BN * 4) {
+                const int row = idx >> 2;
+                *(uint4*)(Bs + buf * BN * 32 + row * 32 + swz_slot(row, idx & 3) * 8) = breg[j];
+            }
+        }
+    };
+
+    f4_t acc[WCH][WPX];
+#pragma unroll
+    for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < WPX; ++pi) acc[ci][pi] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nks = p.nchunks * p.KD * p.KH * p.KW;
+    int kd = 0, kh = 0, kw = 0, c0 = 0;
+    gload(0, 0, 0, 0, 0);
+    sstore(0);
+    __syncthreads();
+
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        const bool more = ks + 1 < nks;
+        if (more) {
+            if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; if (++kd == p.KD) { kd = 0; c0 += 32; } } }
+            gload(kd, kh, kw, c0, ks + 1);
+        }
+        h8_t wf[WCH], af[WPX];
+#pragma unroll
+        for (int ci = 0; ci < WCH; ++ci) {
+            const int row = wch * WCH * 16 + ci * 16 + l15;
+            wf[ci] = *(const h8_t*)(Bs + cur * BN * 32 + row * 32 + swz_slot(row, l4) * 8);
+        }
+#pragma unroll
+        for (int pi = 0; pi < WPX; ++pi) {
+            const int row = wpx * WPX * 16 + pi * 16 + l15;
+            af[pi] = *(const h8_t*)(As + cur * BM * 32 + row * 32 + swz_slot(row, l4) * 8);
+        }
+#pragma unroll
+        for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+            for (int pi = 0; pi < WPX; ++pi)
+                acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ci], af[pi], acc[ci][pi], 0, 0, 0);
+        if (more) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // lane holds, for position column l15 of each 16-block and channel rows l4*4 .. l4*4+3:
+    constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1;
+#pragma unroll
+    for (int pi = 0; pi < WPX; ++pi) {
+        int m = wpx * WPX * 16 + pi * 16 + l15;
+        const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW;
+        const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH;
+        const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD;
+        const int n = tn * (BM >> lgS) + m;
+        if (n >= p.N) continue;
+        float ps = 1.f;
+        if (p.pixscale) ps = p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride];
+#pragma unroll
+        for (int ci = 0; ci < WCH; ci += CSTEP) {
+            const int pb = (n0 + wch * WCH * 16) / 16 + ci;                    // packed 16-row block
+            const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4;        // logical channel base
+            if (cb >= p.Cout) continue;
+            float v[4];
+            if (MODE == MODE_TBLEND) {
+                // adaptive_modulate.py:186  out = mask*(conv(x,w_mod)+bias_param) + (1-mask)*conv(x,W)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = ps * (acc[ci + CSTEP - 1][pi][r] + p.bias[cb + r]) + (1.f - ps) * acc[ci][pi][r];
+            } else if (MODE == MODE_SPADE) {
+                // util.py:295-302  IN(x) * (1 + gamma) + beta
+                float x[4];
+                const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> p.res_shift) * p.res.sH +
+                                (long)(w >> p.res_shift) * p.res.sW + cb;
+                load4(p.res, p.res_f32, xo, x);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* st = p.stats + ((long)n * p.Cout + cb + r) * 2;
+                    const float mean = st[0] * p.stat_cnt_inv;
+                    const float var = fmaxf(st[1] * p.stat_cnt_inv - mean * mean, 0.f);
+                    const float g = acc[ci][pi][r] + p.bias[cb + r];
+                    const float b = acc[ci + CSTEP - 1][pi][r] + p.bias2[cb + r];
+                    v[r] = (x[r] - mean) * rsqrtf(var + p.eps) * (1.f + g) + b;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ci][pi][r] + (p.bias ? p.bias[cb + r] : 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act0, p.slope0);
+
+            if (MODE == MODE_PIXSHUF) {
+                // nn.PixelShuffle(2) + sigmoid (spade_generator.py:36-39,57): c12 = c*4 + i*2 + j
+                const int c = cb >> 2;
+                if (c < 3) {
+                    float* o = (float*)p.out0.p;
+                    const long W2 = 2L * p.W, H2 = 2L * p.H;
+                    const long base = (((long)n * 3 + c) * H2 + 2 * h) * W2 + 2 * w;
+                    *(float2*)(o + base) = make_float2(v[0], v[1]);
+                    *(float2*)(o + base + W2) = make_float2(v[2], v[3]);
+                }
+                continue;
+            }
+            if (MODE != MODE_SPADE && p.res.p) {
+                float rr[4];
+                load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)h * p.res.sH + (long)w * p.res.sW + cb, rr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+            if (MODE == MODE_STD && p.pixscale) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= ps;
+            }
+            if (p.out0.p)
+                store4(p.out0, p.out0_f32, (long)n * p.out0.sN + (long)d * p.out0.sD + (long)h * p.out0.sH + (long)w * p.out0.sW + cb, v);
+            if (p.out1.p) {
+                float u[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = p.s2 ? v[r] * p.s2[cb + r] + p.t2[cb + r] : v[r];
+                    u[r] = apply_act(a, p.act1, p.slope1);
+                }
+                store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u);
+            }
+        }
+    }
+}
+
+template <int WPX, int WCH, int WVP, int WVC, int MODE>
+static int launch_cfg(const ConvParams& p, hipStream_t st)
+{
+    constexpr int BM = WPX * 16 * WVP, BN = WCH * 16 * WVC;
+    if (p.Cout_pad % BN != 0) { cs_set_error("conv: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
+    if ((1 << (p.lgTW + p.lgTH + p.lgTD)) > BM) { cs_set_error("conv: spatial tile exceeds BM"); return -1; }
+    const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(half_t);
+    dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
+    hipLaunchKernelGGL((conv_igemm_kernel<WPX, WCH, WVP, WVC, MODE>), grid, dim3(256), lds, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cs_set_error("conv launch: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st)
+{
+    if (mode == MODE_STD) {
+        switch (cfg) {
+        case CFG_128x128: return launch_cfg<4, 4, 2, 2, MODE_STD>(p, st);
+        case CFG_128x64: return launch_cfg<2, 4, 4, 1, MODE_STD>(p, st);
+        case CFG_256x32: return launch_cfg<4, 2, 4, 1, MODE_STD>(p, st);
+        case CFG_256x16: return launch_cfg<4, 1, 4, 1, MODE_STD>(p, st);
+        }
+    } else if (mode == MODE_TBLEND) {
+        if (cfg == CFG_128x128) return launch_cfg<4, 4, 2, 2, MODE_TBLEND>(p, st);
+    } else if (mode == MODE_SPADE) {
+        if (cfg == CFG_128x128) return launch_cfg<4, 4, 2, 2, MODE_SPADE>(p, st);
+        if (cfg == CFG_128x64) return launch_cfg<2, 4, 4, 1, MODE_SPADE>(p, st);
+    } else if (mode == MODE_PIXSHUF) {
+        if (cfg == CFG_256x16) return launch_cfg<4, 1, 4, 1, MODE_PIXSHUF>(p, st);
+    }
+    cs_set_error("conv: unsupported cfg/mode %d/%d", cfg, mode);
+    return -1;
+}

@@ -1,0 +1,913 @@
+// Host side of the gfx950 CanonSwap engine: weight registry, workspace, per-stage kernel sequencing and
+// the C ABI declared in include/canonswap_hip.h.  Stage order and argument wiring follow
+// src/can_swap_pipeline_e2e.py:242-263 and src/can_swap_e2e.py:286-312 of the reference.
+#include "common.h"
+#include "../../include/canonswap_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+void cs_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cs_last_error(void) { return g_err; }
+extern "C" int cs_abi_version(void) { return 1; }
+
+#define TRY(x) do { if ((x) != 0) return -1; } while (0)
+
+namespace {
+
+constexpr int FD = 16, FH = 64, FW = 64, FC = 32;            // feature volume 32x16x64x64
+constexpr long VOL = (long)FD * FH * FW * FC;                 // 2,097,152 elements
+constexpr long VOX = (long)FD * FH * FW;                      // 65,536 voxels
+constexpr int IMG = 256;
+
+struct Blob { void* p = nullptr; size_t bytes = 0; };
+
+struct ConvL {            // one packed convolution layer
+    const half_t* w = nullptr;
+    const float* b = nullptr;
+    int Cin = 0, Cout_pad = 0, Cout = 0, KD = 1, KH = 1, KW = 1;
+    double macs_per_pos = 0;   // logical (reference) Cin*Cout*taps, for FLOP accounting
+};
+
+struct Affine { const float* s = nullptr; const float* t = nullptr; };
+
+struct TLayer { ConvL fused; ConvL mask; const float* raw; const float* fc; const float* bias; half_t* wmut; };
+
+}  // namespace
+
+struct cs_engine {
+    int dev = 0, maxB = 1;
+    bool finalized = false, identity_set = false;
+    std::map<std::string, Blob> blobs;
+    std::vector<void*> allocs;
+
+    // ---- layers
+    const float *first_w = nullptr, *first_b = nullptr;
+    ConvL f_down0, f_down1, f_second;
+    Affine f_pre0;
+    struct RB3 { ConvL c1, c2; Affine post; } f_rb[6], t_rb[6];
+    const float *cmp_w = nullptr, *cmp_b = nullptr;
+    ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_third, w_fourth;
+    const half_t* occ_w = nullptr; float occ_b = 0.f;
+    TLayer t_l[14];
+    Affine t_pre0;
+    struct S3 { ConvL c1, c2; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];
+    struct RB2 { ConvL c1, c2; Affine pre; } r_rb2[3];
+    ConvL g_fc, g_sh64, g_sh128, g_sh256, g_img;
+    struct GB { ConvL conv; const float *bg, *bb; };
+    struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs; bool learned; int fin, fmid, fout; } g_blk[8];
+
+    // ---- workspace
+    half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
+    float* vs[3]; half_t* va[2];
+    half_t *dm_comp, *dm_l[6], *dm_pre, *dm_pred;
+    float *dm_logits, *dm_deform, *dm_occ;
+    float *kpbuf;
+    half_t *w_t3, *seg16;
+    float* tmask; float* style;
+    float* stats_pool; size_t stats_slots = 0, stats_next = 0; size_t stats_slot_floats = 0;
+    half_t *g_x[2], *g_h64, *g_dx64, *g_a64, *g_a128, *g_a256, *g_h128, *g_xs128, *g_dx128, *g_h1_128, *g_o128;
+    half_t *g_h256, *g_xs256, *g_dx256, *g_h1_256, *g_o256;
+    float *img_a, *img_b;
+
+    // ---- profiling
+    bool prof = false;
+    struct Rec { int fam; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> evpool;
+    size_t evnext = 0;
+    double flops = 0;
+
+    hipEvent_t ev()
+    {
+        if (evnext == evpool.size()) { hipEvent_t e; hipEventCreate(&e); evpool.push_back(e); }
+        return evpool[evnext++];
+    }
+    template <class F> int run(int fam, hipStream_t st, F f)
+    {
+        if (!prof) return f();
+        hipEvent_t a = ev(), b = ev();
+        hipEventRecord(a, st);
+        int r = f();
+        hipEventRecord(b, st);
+        recs.push_back({fam, a, b});
+        return r;
+    }
+    template <class T> int alloc(T** p, size_t n)
+    {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, n * sizeof(T));
+        if (e != hipSuccess) { cs_set_error("hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e)); return -1; }
+        allocs.push_back(q);
+        *p = (T*)q;
+        return 0;
+    }
+    const Blob* find(const std::string& n) const
+    {
+        auto it = blobs.find(n);
+        return it == blobs.end() ? nullptr : &it->second;
+    }
+};
+
+namespace {
+
+int need(cs_engine* e, const std::string& n, size_t bytes, const void** out)
+{
+    const Blob* b = e->find(n);
+    if (!b) { cs_set_error("weights: blob '%s' was not uploaded", n.c_str()); return -1; }
+    if (bytes && b->bytes != bytes) { cs_set_error("weights: blob '%s' has %zu bytes, expected %zu", n.c_str(), b->bytes, bytes); return -1; }
+    *out = b->p;
+    return 0;
+}
+
+int get_conv(cs_engine* e, const std::string& n, int Cin, int Cout_pad, int Cout, int KD, int KH, int KW, int bias_len,
+             double macs, ConvL* L)
+{
+    const int nch = (Cin + 31) / 32;
+    const void* p;
+    TRY(need(e, n + ".w", (size_t)nch * KD * KH * KW * Cout_pad * 32 * sizeof(half_t), &p));
+    L->w = (const half_t*)p;
+    L->b = nullptr;
+    if (bias_len > 0) { TRY(need(e, n + ".b", (size_t)bias_len * sizeof(float), &p)); L->b = (const float*)p; }
+    L->Cin = Cin; L->Cout_pad = Cout_pad; L->Cout = Cout; L->KD = KD; L->KH = KH; L->KW = KW;
+    L->macs_per_pos = macs;
+    return 0;
+}
+
+int get_affine(cs_engine* e, const std::string& n, int len, Affine* a)
+{
+    const void* p;
+    TRY(need(e, n + ".s", (size_t)len * 4, &p)); a->s = (const float*)p;
+    TRY(need(e, n + ".t", (size_t)len * 4, &p)); a->t = (const float*)p;
+    return 0;
+}
+
+int get_f32(cs_engine* e, const std::string& n, int len, const float** out)
+{
+    const void* p;
+    TRY(need(e, n, (size_t)len * 4, &p));
+    *out = (const float*)p;
+    return 0;
+}
+
+TDesc td(void* p, long sN, long sD, long sH, long sW) { return TDesc{p, sN, sD, sH, sW}; }
+// contiguous [N][H][W][C]
+TDesc nhwc(void* p, int H, int W, int C) { return td(p, (long)H * W * C, 0, (long)W * C, C); }
+// feature volume [N][H][W][D][C] seen as a 3-D tensor (d stride = C) or as the 512-channel 2-D view
+TDesc hwdc3(void* p) { return td(p, VOL, FC, (long)FW * FD * FC, (long)FD * FC); }
+TDesc hwdc2(void* p) { return td(p, VOL, 0, (long)FW * FD * FC, (long)FD * FC); }
+// dense-motion tensors [N][D][H][W][stride]
+TDesc dhwc(void* p, int D, int H, int W, int stride) { return td(p, (long)D * H * W * stride, (long)H * W * stride, (long)W * stride, stride); }
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct ConvCall {
+    ConvParams p;
+    int cfg = -1, mode = MODE_STD;
+    double macs_per_pos = 0;
+};
+
+ConvCall mk(const ConvL& L, const void* in, TDesc ind, int N, int D, int H, int W, int up_shift = 0)
+{
+    ConvCall c;
+    memset(&c.p, 0, sizeof(c.p));
+    ConvParams& p = c.p;
+    p.in = (const half_t*)in;
+    p.in_sN = ind.sN; p.in_sD = ind.sD; p.in_sH = ind.sH; p.in_sW = ind.sW;
+    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.Cin = L.Cin; p.nchunks = (L.Cin + 31) / 32; p.up_shift = up_shift;
+    p.KD = L.KD; p.KH = L.KH; p.KW = L.KW; p.PD = L.KD / 2; p.PH = L.KH / 2; p.PW = L.KW / 2;
+    p.wgt = L.w; p.Cout_pad = L.Cout_pad; p.Cout = L.Cout;
+    p.bias = L.b;
+    p.ps_stride = 1;
+    c.macs_per_pos = L.macs_per_pos;
+    return c;
+}
+
+void set_tile(ConvParams& p, int BM, int prefW, int prefH)
+{
+    int tw = p.W < prefW ? p.W : prefW;
+    int th = p.H < prefH ? p.H : prefH;
+    while (tw * th > BM) th >>= 1;
+    int tdd = BM / (tw * th);
+    if (tdd > p.D) tdd = p.D;
+    int tn = BM / (tw * th * tdd);
+    p.lgTW = ilog2(tw); p.lgTH = ilog2(th); p.lgTD = ilog2(tdd);
+    p.nTW = p.W / tw; p.nTH = p.H / th; p.nTD = p.D / tdd; p.nTN = (p.N + tn - 1) / tn;
+}
+
+int pick_cfg(int Cout_pad)
+{
+    if (Cout_pad % 128 == 0) return CFG_128x128;
+    if (Cout_pad % 64 == 0) return CFG_128x64;
+    if (Cout_pad % 32 == 0) return CFG_256x32;
+    return CFG_256x16;
+}
+
+int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
+{
+    if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
+    const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
+    if (!prefW) { prefW = 16; prefH = BM / 16; }
+    set_tile(c.p, BM, prefW, prefH);
+    e->flops += 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
+    return e->run(0, st, [&] { return launch_conv(c.p, c.cfg, c.mode, st); });
+}
+
+float* stats_slot(cs_engine* e)
+{
+    float* p = e->stats_pool + (e->stats_next % e->stats_slots) * e->stats_slot_floats;
+    e->stats_next++;
+    return p;
+}
+
+int zero_stats(cs_engine* e, hipStream_t st)
+{
+    e->stats_next = 0;
+    hipError_t r = hipMemsetAsync(e->stats_pool, 0, e->stats_slots * e->stats_slot_floats * sizeof(float), st);
+    if (r != hipSuccess) { cs_set_error("memset stats: %s", hipGetErrorString(r)); return -1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ F
+// AppearanceFeatureExtractor.forward (appearance_feature_extractor.py:38-48); result: fp32 HWDC in vs[*cur]
+int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Affine* final_post, int final_act, hipStream_t st)
+{
+    // util.py:94-102; a = relu(bn1(x)) is already in va[0]; x (fp32 residual stream) in vs[*cur]
+    for (int i = 0; i < 6; ++i) {
+        ConvCall c1 = mk(rb[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);   // conv1 with norm2 folded, ReLU
+        c1.p.act0 = ACT_RELU;
+        c1.p.out0 = hwdc3(e->va[1]);
+        TRY(go(e, c1, st, 4, 4));
+        const int nxt = (*cur + 1) % 3;
+        ConvCall c2 = mk(rb[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);   // conv2 + x
+        c2.p.res = hwdc3(e->vs[*cur]); c2.p.res_f32 = 1;
+        c2.p.out0 = hwdc3(e->vs[nxt]); c2.p.out0_f32 = 1;
+        c2.p.out1 = hwdc3(e->va[0]);
+        if (i < 5) { c2.p.s2 = rb[i].post.s; c2.p.t2 = rb[i].post.t; c2.p.act1 = ACT_RELU; }
+        else if (final_post) { c2.p.s2 = final_post->s; c2.p.t2 = final_post->t; c2.p.act1 = final_act; }
+        TRY(go(e, c2, st, 4, 4));
+        *cur = nxt;
+    }
+    return 0;
+}
+
+int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
+{
+    TRY(e->run(1, st, [&] { return launch_conv_first(img, e->first_w, e->first_b, e->f_t0, B, IMG, IMG, st); }));
+    e->flops += 2.0 * 3 * 64 * 9 * (double)B * IMG * IMG;
+    ConvCall d0 = mk(e->f_down0, e->f_t0, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
+    d0.p.act0 = ACT_RELU; d0.p.out0 = nhwc(e->f_t1, 256, 256, 128);
+    TRY(go(e, d0, st));
+    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }));
+    ConvCall d1 = mk(e->f_down1, e->f_p0, nhwc(nullptr, 128, 128, 128), B, 1, 128, 128);
+    d1.p.act0 = ACT_RELU; d1.p.out0 = nhwc(e->f_t2, 128, 128, 256);
+    TRY(go(e, d1, st));
+    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }));
+    *cur = 0;
+    ConvCall s = mk(e->f_second, e->f_p1, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);   // 1x1 -> the 32x16 volume
+    s.p.out0 = hwdc2(e->vs[0]); s.p.out0_f32 = 1;
+    s.p.out1 = hwdc2(e->va[0]); s.p.s2 = e->f_pre0.s; s.p.t2 = e->f_pre0.t; s.p.act1 = ACT_RELU;
+    TRY(go(e, s, st));
+    return run_resblocks3d(e, e->f_rb, B, cur, nullptr, ACT_NONE, st);
+}
+
+// ------------------------------------------------------------------------------------------------ W
+// DenseMotionNetwork.forward (dense_motion.py:67-104). feat: fp32 HWDC. Leaves deformation / occlusion in
+// e->dm_deform / e->dm_occ.
+int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st)
+{
+    TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, B, FD, FH, FW, st); }));
+    e->flops += (2.0 * 32 * 4 * VOX + 2.0 * 2272 * 49 * 4096) * B;   // compress + occlusion (launched below)
+    // hourglass input lands in channels [32,144) of the level-0 concat buffer (util.py:255-264 cat order)
+    TRY(e->run(1, st, [&] { return launch_dm_sparse(e->dm_comp, kp_d, kp_s, e->dm_l[0] + 32, 144, B, FD, FH, FW, st); }));
+    static const int cin[5] = {112, 64, 128, 256, 512}, cout[5] = {64, 128, 256, 512, 1024};
+    static const int lw[6] = {144, 128, 256, 512, 1024, 1024};   // concat widths per level
+    static const int skip_off[6] = {32, 64, 128, 256, 512, 0};   // channel offset of the skip part
+    for (int i = 0; i < 5; ++i) {       // Encoder: DownBlock3d (util.py:185-190)
+        const int S = 64 >> i;
+        ConvCall c = mk(e->w_enc[i], e->dm_l[i] + skip_off[i], dhwc(nullptr, FD, S, S, lw[i]), B, FD, S, S);
+        (void)cin;
+        c.p.act0 = ACT_RELU;
+        c.p.out0 = dhwc(e->dm_pre, FD, S, S, cout[i]);
+        TRY(go(e, c, st));
+        TDesc o = dhwc(e->dm_l[i + 1] + skip_off[i + 1], FD, S / 2, S / 2, lw[i + 1]);
+        TRY(e->run(1, st, [&] { return launch_avgpool(e->dm_pre, B, FD, S, S, cout[i], o, st); }));
+    }
+    for (int i = 0; i < 5; ++i) {       // Decoder: UpBlock3d (util.py:142-147), nearest x(1,2,2) folded into addressing
+        const int lv = 5 - i, S = 64 >> (lv - 1), Si = S / 2;
+        ConvCall c = mk(e->w_dec[i], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, S, S, 1);
+        c.p.act0 = ACT_RELU;
+        c.p.out0 = dhwc(e->dm_l[lv - 1], FD, S, S, lw[lv - 1]);
+        TRY(go(e, c, st));
+    }
+    ConvCall t = mk(e->w_tail, e->dm_l[0], dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // util.py:261-263
+    t.p.act0 = ACT_RELU; t.p.out0 = dhwc(e->dm_pred, FD, 64, 64, 144);
+    TRY(go(e, t, st));
+    ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
+    m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 32); m.p.out0_f32 = 1;
+    TRY(go(e, m, st));
+    TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, 32, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_dm_occlusion(e->dm_pred, 144, e->occ_w, e->occ_b, e->dm_occ, B, FD, FH, FW, st); }));
+    return 0;
+}
+
+// warp_out (warping_network.py:64-71): vol16 = fp16 HWDC volume -> seg16 [B][64][64][256]
+int run_warp_out(cs_engine* e, int B, const half_t* vol16, const float* occ, hipStream_t st)
+{
+    ConvCall t3 = mk(e->w_third, vol16, hwdc2(nullptr), B, 1, 64, 64);
+    t3.p.act0 = ACT_LRELU; t3.p.slope0 = 0.01f;
+    t3.p.out0 = nhwc(e->w_t3, 64, 64, 256);
+    TRY(go(e, t3, st));
+    ConvCall f4 = mk(e->w_fourth, e->w_t3, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
+    f4.p.pixscale = occ;
+    f4.p.out0 = nhwc(e->seg16, 64, 64, 256);
+    return go(e, f4, st);
+}
+
+// ------------------------------------------------------------------------------------------------ T
+// transfer_model2.forward (adaptive_modulate.py:522-554). x: fp32 vs[*cur] + fp16 copy va[0].
+// On exit: fp32 result in vs[*cur], fp16 copy in va[0].
+int run_T(cs_engine* e, int B, int* cur, hipStream_t st)
+{
+    if (!e->identity_set) { cs_set_error("cs_swap: cs_set_identity has not been called"); return -1; }
+    for (int i = 0; i < 7; ++i) {
+        for (int j = 0; j < 2; ++j) {   // ResnetBlock_Adaptive2D: conv1 -> ReLU -> conv2, + x (:337-349)
+            TLayer& L = e->t_l[i * 2 + j];
+            const half_t* in = e->va[j];
+            ConvCall mc = mk(L.mask, in, hwdc2(nullptr), B, 1, 64, 64);       // mask_conv + sigmoid (:118-121,176)
+            mc.p.act0 = ACT_SIGMOID;
+            mc.p.out0 = td(e->tmask, 4096L * 4, 0, 64 * 4, 4); mc.p.out0_f32 = 1;
+            TRY(go(e, mc, st));
+            ConvCall fc = mk(L.fused, in, hwdc2(nullptr), B, 1, 64, 64);      // [W ; w_mod] fused, blend epilogue
+            fc.mode = MODE_TBLEND;
+            fc.p.Cout = 512;
+            fc.p.bias = L.bias;
+            fc.p.pixscale = e->tmask; fc.p.ps_stride = 4;
+            if (j == 0) {
+                fc.p.act0 = ACT_RELU;
+                fc.p.out0 = hwdc2(e->va[1]);
+            } else {
+                const int nxt = (*cur + 1) % 3;
+                fc.p.res = hwdc2(e->vs[*cur]); fc.p.res_f32 = 1;
+                fc.p.out0 = hwdc2(e->vs[nxt]); fc.p.out0_f32 = 1;
+                fc.p.out1 = hwdc2(e->va[0]);
+                if (i == 6) { fc.p.s2 = e->t_pre0.s; fc.p.t2 = e->t_pre0.t; fc.p.act1 = ACT_RELU; }
+                *cur = nxt;
+            }
+            TRY(go(e, fc, st));
+        }
+    }
+    return run_resblocks3d(e, e->t_rb, B, cur, nullptr, ACT_NONE, st);   // last block leaves the raw fp16 copy in va[0]
+}
+
+// ------------------------------------------------------------------------------------------------ R
+// G3d.forward (adaptive_modulate.py:721-733). x: fp32 vs[*cur] + fp16 va[0]; result fp32 in vs[*cur].
+int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
+{
+    const float cnt_inv = 1.f / (float)VOX;
+    for (int i = 0; i < 3; ++i) {   // ResBlock3D_stage3_leak (util.py:528-544)
+        const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
+        ConvCall c1 = mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
+        c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
+        TRY(go(e, c1, st, 4, 4));
+        float* s1 = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(e->vs[y], 1, B, VOX, 32, s1, st); }));
+        TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, cnt_inv, 1e-5f, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
+                                                       e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }));
+        ConvCall c2 = mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
+        c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
+        TRY(go(e, c2, st, 4, 4));
+        float* s2 = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(e->vs[y], 1, B, VOX, 32, s2, st); }));
+        const bool pre = (i == 2 && last_pre);
+        TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s2, cnt_inv, 1e-5f, blk[i].g2, blk[i].b2, e->vs[*cur], 0.01f,
+                                                       e->vs[nxt], e->va[0], pre ? last_pre->s : nullptr, pre ? last_pre->t : nullptr,
+                                                       512, pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st); }));
+        *cur = nxt;
+    }
+    return 0;
+}
+
+int run_R(cs_engine* e, int B, int* cur, hipStream_t st)
+{
+    TRY(run_stage3(e, e->r_s1, B, cur, &e->r_rb2[0].pre, st));
+    for (int i = 0; i < 3; ++i) {   // ResBlock2d on the 512-channel view (util.py:120-128), LeakyReLU(0.01)
+        ConvCall c1 = mk(e->r_rb2[i].c1, e->va[0], hwdc2(nullptr), B, 1, 64, 64);
+        c1.p.act0 = ACT_LRELU; c1.p.slope0 = 0.01f;
+        c1.p.out0 = hwdc2(e->va[1]);
+        TRY(go(e, c1, st));
+        const int nxt = (*cur + 1) % 3;
+        ConvCall c2 = mk(e->r_rb2[i].c2, e->va[1], hwdc2(nullptr), B, 1, 64, 64);
+        c2.p.res = hwdc2(e->vs[*cur]); c2.p.res_f32 = 1;
+        c2.p.out0 = hwdc2(e->vs[nxt]); c2.p.out0_f32 = 1;
+        c2.p.out1 = hwdc2(e->va[0]);
+        if (i < 2) { c2.p.s2 = e->r_rb2[i + 1].pre.s; c2.p.t2 = e->r_rb2[i + 1].pre.t; c2.p.act1 = ACT_LRELU; c2.p.slope1 = 0.01f; }
+        TRY(go(e, c2, st));
+        *cur = nxt;
+    }
+    return run_stage3(e, e->r_s3, B, cur, nullptr, st);
+}
+
+// ------------------------------------------------------------------------------------------------ G
+// SPADEDecoder.forward (spade_generator.py:41-59). seg16: [B][64][64][256] fp16 -> img fp32 Bx3x512x512
+int spade_gb(cs_engine* e, const cs_engine::GB& gb, int C, const half_t* actv, int astride, int aoff, int B, int S,
+             const half_t* x, int xshift, const float* stats, int act, half_t* out, hipStream_t st)
+{
+    // SPADE.forward (util.py:295-302): gamma/beta convs fused, modulation applied in the epilogue
+    ConvCall c = mk(gb.conv, actv + aoff, nhwc(nullptr, S, S, astride), B, 1, S, S);
+    c.mode = MODE_SPADE;
+    c.p.Cout = C;
+    c.p.bias = gb.bg; c.p.bias2 = gb.bb;
+    const int Sx = S >> xshift;
+    c.p.res = nhwc((void*)x, Sx, Sx, C); c.p.res_f32 = 0; c.p.res_shift = xshift;
+    c.p.stats = stats; c.p.stat_cnt_inv = 1.f / (float)(Sx * Sx); c.p.eps = 1e-5f;
+    c.p.act0 = act; c.p.slope0 = 0.2f;
+    c.p.out0 = nhwc(out, S, S, C);
+    return go(e, c, st);
+}
+
+int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
+{
+    TRY(zero_stats(e, st));
+    ConvCall fc = mk(e->g_fc, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
+    fc.p.out0 = nhwc(e->g_x[0], 64, 64, 512);
+    TRY(go(e, fc, st));
+    // all 18 mlp_shared convs depend only on seg (util.py:298): three fused launches
+    ConvCall s64 = mk(e->g_sh64, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
+    s64.p.act0 = ACT_RELU; s64.p.out0 = nhwc(e->g_a64, 64, 64, 1536);
+    TRY(go(e, s64, st));
+    ConvCall s128 = mk(e->g_sh128, seg, nhwc(nullptr, 64, 64, 256), B, 1, 128, 128, 1);
+    s128.p.act0 = ACT_RELU; s128.p.out0 = nhwc(e->g_a128, 128, 128, 384);
+    TRY(go(e, s128, st));
+    ConvCall s256 = mk(e->g_sh256, seg, nhwc(nullptr, 64, 64, 256), B, 1, 256, 256, 2);
+    s256.p.act0 = ACT_RELU; s256.p.out0 = nhwc(e->g_a256, 256, 256, 384);
+    TRY(go(e, s256, st));
+
+    int cx = 0;
+    for (int b = 0; b < 6; ++b) {   // SPADEResnetBlock 512->512 @64x64 (util.py:329-344)
+        const cs_engine::SpadeBlk& K = e->g_blk[b];
+        float* st0 = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_x[cx], 0, B, 4096, 512, st0, st); }));
+        TRY(spade_gb(e, K.n0, 512, e->g_a64, 1536, (b * 2) * 128, B, 64, e->g_x[cx], 0, st0, ACT_LRELU, e->g_h64, st));
+        ConvCall c0 = mk(K.c0, e->g_h64, nhwc(nullptr, 64, 64, 512), B, 1, 64, 64);
+        c0.p.out0 = nhwc(e->g_dx64, 64, 64, 512);
+        TRY(go(e, c0, st));
+        float* st1 = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_dx64, 0, B, 4096, 512, st1, st); }));
+        TRY(spade_gb(e, K.n1, 512, e->g_a64, 1536, (b * 2 + 1) * 128, B, 64, e->g_dx64, 0, st1, ACT_LRELU, e->g_h64, st));
+        ConvCall c1 = mk(K.c1, e->g_h64, nhwc(nullptr, 64, 64, 512), B, 1, 64, 64);
+        c1.p.res = nhwc(e->g_x[cx], 64, 64, 512);
+        c1.p.out0 = nhwc(e->g_x[cx ^ 1], 64, 64, 512);
+        TRY(go(e, c1, st));
+        cx ^= 1;
+    }
+    // up_0: nn.Upsample(x2) folded into addressing; 512 -> 256 @128 (learned shortcut)
+    {
+        const cs_engine::SpadeBlk& K = e->g_blk[6];
+        const half_t* x = e->g_x[cx];
+        float* sx = stats_slot(e);     // nearest up-sampling leaves per-channel mean / variance unchanged
+        TRY(e->run(1, st, [&] { return launch_chan_stats(x, 0, B, 4096, 512, sx, st); }));
+        TRY(spade_gb(e, K.ns, 512, e->g_a128, 384, 256, B, 128, x, 1, sx, ACT_NONE, e->g_h128, st));
+        ConvCall cs = mk(K.cs, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
+        cs.p.out0 = nhwc(e->g_xs128, 128, 128, 256);
+        TRY(go(e, cs, st));
+        TRY(spade_gb(e, K.n0, 512, e->g_a128, 384, 0, B, 128, x, 1, sx, ACT_LRELU, e->g_h128, st));
+        ConvCall c0 = mk(K.c0, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
+        c0.p.out0 = nhwc(e->g_dx128, 128, 128, 256);
+        TRY(go(e, c0, st));
+        float* s1 = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_dx128, 0, B, 16384, 256, s1, st); }));
+        TRY(spade_gb(e, K.n1, 256, e->g_a128, 384, 128, B, 128, e->g_dx128, 0, s1, ACT_LRELU, e->g_h1_128, st));
+        ConvCall c1 = mk(K.c1, e->g_h1_128, nhwc(nullptr, 128, 128, 256), B, 1, 128, 128);
+        c1.p.res = nhwc(e->g_xs128, 128, 128, 256);
+        c1.p.out0 = nhwc(e->g_o128, 128, 128, 256);
+        TRY(go(e, c1, st));
+    }
+    // up_1: 256 -> 64 @256
+    {
+        const cs_engine::SpadeBlk& K = e->g_blk[7];
+        const half_t* x = e->g_o128;
+        float* sx = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(x, 0, B, 16384, 256, sx, st); }));
+        TRY(spade_gb(e, K.ns, 256, e->g_a256, 384, 256, B, 256, x, 1, sx, ACT_NONE, e->g_h256, st));
+        ConvCall cs = mk(K.cs, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
+        cs.p.out0 = nhwc(e->g_xs256, 256, 256, 64);
+        TRY(go(e, cs, st));
+        TRY(spade_gb(e, K.n0, 256, e->g_a256, 384, 0, B, 256, x, 1, sx, ACT_LRELU, e->g_h256, st));
+        ConvCall c0 = mk(K.c0, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
+        c0.p.out0 = nhwc(e->g_dx256, 256, 256, 64);
+        TRY(go(e, c0, st));
+        float* s1 = stats_slot(e);
+        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_dx256, 0, B, 65536, 64, s1, st); }));
+        TRY(spade_gb(e, K.n1, 64, e->g_a256, 384, 128, B, 256, e->g_dx256, 0, s1, ACT_LRELU, e->g_h1_256, st));
+        ConvCall c1 = mk(K.c1, e->g_h1_256, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
+        c1.p.res = nhwc(e->g_xs256, 256, 256, 64);
+        c1.p.out1 = nhwc(e->g_o256, 256, 256, 64);      // leaky_relu(x, 0.2) feeding conv_img (spade_generator.py:56)
+        c1.p.act1 = ACT_LRELU; c1.p.slope1 = 0.2f;
+        TRY(go(e, c1, st));
+    }
+    ConvCall ci = mk(e->g_img, e->g_o256, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
+    ci.mode = MODE_PIXSHUF; ci.cfg = CFG_256x16;
+    ci.p.Cout = 16;
+    ci.p.act0 = ACT_SIGMOID;
+    ci.p.out0 = td(img, 0, 0, 0, 0); ci.p.out0_f32 = 1;
+    return go(e, ci, st);
+}
+
+int check(cs_engine* e, int B)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    if (!e->finalized) { cs_set_error("cs_finalize_weights has not been called"); return -1; }
+    if (B < 1 || B > e->maxB) { cs_set_error("batch %d outside [1, %d]", B, e->maxB); return -1; }
+    return 0;
+}
+
+int copy_dd(void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    if (r != hipSuccess) { cs_set_error("memcpy d2d: %s", hipGetErrorString(r)); return -1; }
+    return 0;
+}
+
+int to_hwdc(cs_engine* e, int B, const float* f, float* out32, half_t* out16, hipStream_t st)
+{
+    return e->run(1, st, [&] { return launch_ncdhw_to_hwdc(f, out32, out16, nullptr, nullptr, ACT_NONE, 0.f, B, FC, FD, FH, FW, st); });
+}
+int from_hwdc(cs_engine* e, int B, const float* in, float* out, hipStream_t st)
+{
+    return e->run(1, st, [&] { return launch_hwdc_to_ncdhw(in, out, B, FC, FD, FH, FW, st); });
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
+{
+    if (!out || max_batch < 1) { cs_set_error("cs_create: bad arguments"); return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) {
+        cs_set_error("cs_create: HIP device %d not available (%d devices visible)", device_id, ndev);
+        return -1;
+    }
+    CS_CHECK_HIP(hipSetDevice(device_id));
+    cs_engine* e = new cs_engine();
+    e->dev = device_id; e->maxB = max_batch;
+    const size_t B = (size_t)max_batch;
+#define A(ptr, n) if (e->alloc(&e->ptr, (size_t)(n)) != 0) { cs_destroy(e); return -1; }
+    A(f_t0, B * 65536 * 64); A(f_t1, B * 65536 * 128); A(f_p0, B * 16384 * 128); A(f_t2, B * 16384 * 256); A(f_p1, B * 4096 * 256);
+    for (int i = 0; i < 3; ++i) A(vs[i], B * VOL);
+    for (int i = 0; i < 2; ++i) A(va[i], B * VOL);
+    A(dm_comp, B * VOX * 4);
+    static const long lsz[6] = {65536L * 144, 16L * 1024 * 128, 16L * 256 * 256, 16L * 64 * 512, 16L * 16 * 1024, 16L * 4 * 1024};
+    for (int i = 0; i < 6; ++i) A(dm_l[i], B * lsz[i]);
+    A(dm_pre, B * VOX * 64); A(dm_pred, B * VOX * 144);
+    A(dm_logits, B * VOX * 32); A(dm_deform, B * VOX * 3); A(dm_occ, B * 4096);
+    A(kpbuf, B * 21 * 3 * 2);
+    A(w_t3, B * 4096 * 256); A(seg16, B * 4096 * 256);
+    A(tmask, B * 4096 * 4); A(style, 14 * 512);
+    e->stats_slots = 48; e->stats_slot_floats = B * 512 * 2;
+    A(stats_pool, e->stats_slots * e->stats_slot_floats);
+    for (int i = 0; i < 2; ++i) A(g_x[i], B * 4096 * 512);
+    A(g_h64, B * 4096 * 512); A(g_dx64, B * 4096 * 512); A(g_a64, B * 4096 * 1536);
+    A(g_a128, B * 16384 * 384); A(g_a256, B * 65536 * 384);
+    A(g_h128, B * 16384 * 512); A(g_xs128, B * 16384 * 256); A(g_dx128, B * 16384 * 256); A(g_h1_128, B * 16384 * 256);
+    A(g_o128, B * 16384 * 256);
+    A(g_h256, B * 65536 * 256); A(g_xs256, B * 65536 * 64); A(g_dx256, B * 65536 * 64); A(g_h1_256, B * 65536 * 64);
+    A(g_o256, B * 65536 * 64);
+    A(img_a, B * 3 * 512 * 512); A(img_b, B * 3 * 512 * 512);
+#undef A
+    // the concat buffers carry zero pad channels that are never written: clear once
+    CS_CHECK_HIP(hipMemset(e->dm_l[0], 0, B * lsz[0] * sizeof(half_t)));
+    CS_CHECK_HIP(hipMemset(e->dm_pred, 0, B * VOX * 144 * sizeof(half_t)));
+    *out = e;
+    return 0;
+}
+
+extern "C" void cs_destroy(cs_engine* e)
+{
+    if (!e) return;
+    hipSetDevice(e->dev);
+    hipDeviceSynchronize();
+    for (void* p : e->allocs) hipFree(p);
+    for (auto& kv : e->blobs) hipFree(kv.second.p);
+    for (hipEvent_t ev : e->evpool) hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int cs_upload(cs_engine* e, const char* name, const void* host_ptr, size_t nbytes)
+{
+    if (!e || !name || !host_ptr || !nbytes) { cs_set_error("cs_upload: bad arguments"); return -1; }
+    CS_CHECK_HIP(hipSetDevice(e->dev));
+    Blob& b = e->blobs[name];
+    if (b.p) { hipFree(b.p); b.p = nullptr; }
+    CS_CHECK_HIP(hipMalloc(&b.p, nbytes));
+    b.bytes = nbytes;
+    CS_CHECK_HIP(hipMemcpy(b.p, host_ptr, nbytes, hipMemcpyHostToDevice));
+    e->finalized = false;
+    return 0;
+}
+
+extern "C" int cs_finalize_weights(cs_engine* e)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    char n[96];
+    // ---- F
+    TRY(get_f32(e, "F.first.w", 64 * 27, &e->first_w)); TRY(get_f32(e, "F.first.b", 64, &e->first_b));
+    TRY(get_conv(e, "F.down0", 64, 128, 128, 1, 3, 3, 128, 64.0 * 128 * 9, &e->f_down0));
+    TRY(get_conv(e, "F.down1", 128, 256, 256, 1, 3, 3, 256, 128.0 * 256 * 9, &e->f_down1));
+    TRY(get_conv(e, "F.second", 256, 512, 512, 1, 1, 1, 512, 256.0 * 512, &e->f_second));
+    TRY(get_affine(e, "F.pre0", 512, &e->f_pre0));
+    for (int which = 0; which < 2; ++which) {
+        cs_engine::RB3* rb = which ? e->t_rb : e->f_rb;
+        const char* pre = which ? "T" : "F";
+        for (int i = 0; i < 6; ++i) {
+            snprintf(n, sizeof n, "%s.rb%d.c1", pre, i); TRY(get_conv(e, n, 32, 32, 32, 3, 3, 3, 32, 32.0 * 32 * 27, &rb[i].c1));
+            snprintf(n, sizeof n, "%s.rb%d.c2", pre, i); TRY(get_conv(e, n, 32, 32, 32, 3, 3, 3, 32, 32.0 * 32 * 27, &rb[i].c2));
+            if (i < 5) { snprintf(n, sizeof n, "%s.rb%d.post", pre, i); TRY(get_affine(e, n, 32, &rb[i].post)); }
+        }
+    }
+    // first conv of F (3->64 @256^2) is outside launch_conv: account its FLOPs where it is launched? keep simple: not counted
+    // ---- W
+    TRY(get_f32(e, "W.compress.w", 128, &e->cmp_w)); TRY(get_f32(e, "W.compress.b", 4, &e->cmp_b));
+    static const int eci[5] = {112, 64, 128, 256, 512}, eco[5] = {64, 128, 256, 512, 1024};
+    static const int ecr[5] = {110, 64, 128, 256, 512};
+    static const int dci[5] = {1024, 1024, 512, 256, 128}, dco[5] = {512, 256, 128, 64, 32};
+    for (int i = 0; i < 5; ++i) {
+        snprintf(n, sizeof n, "W.enc%d", i); TRY(get_conv(e, n, eci[i], eco[i], eco[i], 3, 3, 3, eco[i], (double)ecr[i] * eco[i] * 27, &e->w_enc[i]));
+        snprintf(n, sizeof n, "W.dec%d", i); TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 3, 3, dco[i], (double)dci[i] * dco[i] * 27, &e->w_dec[i]));
+    }
+    TRY(get_conv(e, "W.tail", 144, 192, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
+    TRY(get_conv(e, "W.mask", 144, 32, 32, 7, 7, 7, 32, 142.0 * 22 * 343, &e->w_mask));
+    { const void* p; TRY(need(e, "W.occ.w", (size_t)16 * 49 * 144 * 2, &p)); e->occ_w = (const half_t*)p;
+      const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
+      CS_CHECK_HIP(hipMemcpy(&e->occ_b, b->p, 4, hipMemcpyDeviceToHost)); }
+    TRY(get_conv(e, "W.third", 512, 256, 256, 1, 3, 3, 256, 512.0 * 256 * 9, &e->w_third));
+    TRY(get_conv(e, "W.fourth", 256, 256, 256, 1, 1, 1, 256, 256.0 * 256, &e->w_fourth));
+    // ---- T
+    for (int i = 0; i < 14; ++i) {
+        TLayer& L = e->t_l[i];
+        snprintf(n, sizeof n, "T.b%d.c%d", i / 2, i % 2 + 1);
+        std::string base = n;
+        TRY(get_conv(e, base, 512, 1024, 512, 1, 3, 3, 0, 2.0 * 512 * 512 * 9, &L.fused));
+        L.wmut = (half_t*)L.fused.w;
+        TRY(get_conv(e, base + ".mask", 512, 16, 4, 1, 3, 3, 4, 512.0 * 1 * 9, &L.mask));
+        TRY(get_f32(e, base + ".raw", 512 * 9 * 512, &L.raw));
+        TRY(get_f32(e, base + ".fc", 2 * (512 * 512 + 512), &L.fc));
+        TRY(get_f32(e, base + ".bias", 512, &L.bias));
+    }
+    TRY(get_affine(e, "T.pre0", 512, &e->t_pre0));
+    // ---- R
+    for (int which = 0; which < 2; ++which) {
+        cs_engine::S3* s = which ? e->r_s3 : e->r_s1;
+        for (int i = 0; i < 3; ++i) {
+            snprintf(n, sizeof n, "R.s%d.%d", which ? 3 : 1, i);
+            std::string b = n;
+            TRY(get_conv(e, b + ".c1", 32, 32, 32, 3, 3, 3, 32, 32.0 * 32 * 27, &s[i].c1));
+            TRY(get_conv(e, b + ".c2", 32, 32, 32, 3, 3, 3, 32, 32.0 * 32 * 27, &s[i].c2));
+            TRY(get_f32(e, b + ".gn1.w", 32, &s[i].g1)); TRY(get_f32(e, b + ".gn1.b", 32, &s[i].b1));
+            TRY(get_f32(e, b + ".gn2.w", 32, &s[i].g2)); TRY(get_f32(e, b + ".gn2.b", 32, &s[i].b2));
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        snprintf(n, sizeof n, "R.rb2.%d", i);
+        std::string b = n;
+        TRY(get_conv(e, b + ".c1", 512, 512, 512, 1, 3, 3, 512, 512.0 * 512 * 9, &e->r_rb2[i].c1));
+        TRY(get_conv(e, b + ".c2", 512, 512, 512, 1, 3, 3, 512, 512.0 * 512 * 9, &e->r_rb2[i].c2));
+        TRY(get_affine(e, b + ".pre", 512, &e->r_rb2[i].pre));
+    }
+    // ---- G
+    TRY(get_conv(e, "G.fc", 256, 512, 512, 1, 3, 3, 512, 256.0 * 512 * 9, &e->g_fc));
+    TRY(get_conv(e, "G.shared64", 256, 1536, 1536, 1, 3, 3, 1536, 256.0 * 1536 * 9, &e->g_sh64));
+    TRY(get_conv(e, "G.shared128", 256, 384, 384, 1, 3, 3, 384, 256.0 * 384 * 9, &e->g_sh128));
+    TRY(get_conv(e, "G.shared256", 256, 384, 384, 1, 3, 3, 384, 256.0 * 384 * 9, &e->g_sh256));
+    auto get_gb = [&](const std::string& b, int C, cs_engine::GB* gb) -> int {
+        const int pad = ((2 * C + 127) / 128) * 128;
+        TRY(get_conv(e, b, 128, pad, C, 1, 3, 3, 0, 128.0 * 2 * C * 9, &gb->conv));
+        TRY(get_f32(e, b + ".bg", C, &gb->bg)); TRY(get_f32(e, b + ".bb", C, &gb->bb));
+        return 0;
+    };
+    for (int k = 0; k < 8; ++k) {
+        cs_engine::SpadeBlk& K = e->g_blk[k];
+        std::string b;
+        if (k < 6) { snprintf(n, sizeof n, "G.m%d", k); b = n; K.fin = 512; K.fout = 512; }
+        else if (k == 6) { b = "G.up0"; K.fin = 512; K.fout = 256; }
+        else { b = "G.up1"; K.fin = 256; K.fout = 64; }
+        K.fmid = K.fin < K.fout ? K.fin : K.fout;
+        K.learned = K.fin != K.fout;
+        TRY(get_gb(b + ".n0", K.fin, &K.n0));
+        TRY(get_gb(b + ".n1", K.fmid, &K.n1));
+        TRY(get_conv(e, b + ".c0", K.fin, K.fmid, K.fmid, 1, 3, 3, K.fmid, (double)K.fin * K.fmid * 9, &K.c0));
+        TRY(get_conv(e, b + ".c1", K.fmid, K.fout, K.fout, 1, 3, 3, K.fout, (double)K.fmid * K.fout * 9, &K.c1));
+        if (K.learned) {
+            TRY(get_gb(b + ".ns", K.fin, &K.ns));
+            TRY(get_conv(e, b + ".cs", K.fin, K.fout, K.fout, 1, 1, 1, K.fout, (double)K.fin * K.fout, &K.cs));
+        }
+    }
+    TRY(get_conv(e, "G.img", 64, 16, 16, 1, 3, 3, 16, 64.0 * 12 * 9, &e->g_img));
+    e->finalized = true;
+    return 0;
+}
+
+extern "C" int cs_set_identity(cs_engine* e, int slot, const float* id, void* stream)
+{
+    if (!e || !e->finalized) { cs_set_error("cs_set_identity: engine not finalized"); return -1; }
+    if (slot != 0) { cs_set_error("cs_set_identity: only slot 0 is available"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    CS_CHECK_HIP(hipSetDevice(e->dev));
+    for (int i = 0; i < 14; ++i) {
+        TLayer& L = e->t_l[i];
+        TRY(e->run(1, st, [&] { return launch_t_style(id, L.fc, e->style + i * 512, 1, st); }));
+        TRY(e->run(1, st, [&] { return launch_t_modulate(L.raw, e->style + i * 512, L.wmut, i, st); }));
+    }
+    e->identity_set = true;
+    return 0;
+}
+
+extern "C" int cs_extract_feature_3d(cs_engine* e, int B, const float* img, float* f_out, void* stream)
+{
+    TRY(check(e, B));
+    hipStream_t st = (hipStream_t)stream;
+    int cur = 0;
+    TRY(run_F(e, B, img, &cur, st));
+    return from_hwdc(e, B, e->vs[cur], f_out, st);
+}
+
+extern "C" int cs_warp(cs_engine* e, int B, const float* f, const float* kp_source, const float* kp_driving, float* f_out,
+                       float* occ_out, void* stream)
+{
+    TRY(check(e, B));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, e->vs[1], nullptr, B, FD, FH, FW, st); }));
+    TRY(from_hwdc(e, B, e->vs[1], f_out, st));
+    if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
+    return 0;
+}
+
+extern "C" int cs_warp_out(cs_engine* e, int B, const float* f, const float* occ, float* seg_out, void* stream)
+{
+    TRY(check(e, B));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(to_hwdc(e, B, f, nullptr, e->va[0], st));
+    TRY(run_warp_out(e, B, e->va[0], occ, st));
+    return e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); });
+}
+
+extern "C" int cs_swap(cs_engine* e, int slot, int B, const float* f, float* f_out, void* stream)
+{
+    TRY(check(e, B));
+    if (slot != 0) { cs_set_error("cs_swap: only slot 0 is available"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    int cur = 0;
+    TRY(to_hwdc(e, B, f, e->vs[0], e->va[0], st));
+    TRY(run_T(e, B, &cur, st));
+    return from_hwdc(e, B, e->vs[cur], f_out, st);
+}
+
+extern "C" int cs_refine(cs_engine* e, int B, const float* f, float* f_out, void* stream)
+{
+    TRY(check(e, B));
+    hipStream_t st = (hipStream_t)stream;
+    int cur = 0;
+    TRY(to_hwdc(e, B, f, e->vs[0], e->va[0], st));
+    TRY(zero_stats(e, st));
+    TRY(run_R(e, B, &cur, st));
+    return from_hwdc(e, B, e->vs[cur], f_out, st);
+}
+
+extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float* kp_driving, const float* kp_source,
+                               float* occ_out, float* deformation_out, float* seg_out, void* stream)
+{
+    TRY(check(e, B));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }));
+    TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
+    if (seg_out) TRY(e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }));
+    if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
+    if (deformation_out) TRY(copy_dd(deformation_out, e->dm_deform, (size_t)B * VOX * 3 * 4, st));
+    return 0;
+}
+
+extern "C" int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img_out, void* stream)
+{
+    TRY(check(e, B));
+    hipStream_t st = (hipStream_t)stream;
+    TRY(e->run(1, st, [&] { return launch_nchw_to_nhwc16(seg, e->seg16, B, 256, 4096, st); }));
+    return run_G(e, B, e->seg16, img_out, st);
+}
+
+extern "C" int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W, void* stream)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_pack_u8(img, out, B, 3, H, W, st); });
+}
+
+extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
+                              float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream)
+{
+    TRY(check(e, B));
+    if (slot != 0) { cs_set_error("cs_swap_frames: only slot 0 is available"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    int cur = 0;
+    TRY(run_F(e, B, img, &cur, st));                                                      // :242 f_s
+    // :244 warp(f_s, kp_source = x_t, kp_driving = x_can)
+    TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_can, /*kp_s*/ x_t, nullptr, st));
+    const int nxt = (cur + 1) % 3;
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, e->vs[nxt], e->va[0], B, FD, FH, FW, st); }));
+    cur = nxt;
+    // the first warp's occlusion map is reused by the debug decodes (:248,:257); keep a copy in tmask-free storage
+    float* occ1 = e->img_b;   // B*4096 floats fit easily
+    if (rec_can || swap_can) TRY(copy_dd(occ1, e->dm_occ, (size_t)B * 4096 * 4, st));
+    if (rec_can) {                                                                          // :248
+        TRY(run_warp_out(e, B, e->va[0], occ1, st));
+        TRY(run_G(e, B, e->seg16, rec_can, st));
+    }
+    TRY(run_T(e, B, &cur, st));                                                             // :253
+    if (swap_can) {                                                                         // :257
+        TRY(run_warp_out(e, B, e->va[0], occ1, st));
+        TRY(run_G(e, B, e->seg16, swap_can, st));
+    }
+    TRY(zero_stats(e, st));
+    TRY(run_R(e, B, &cur, st));                                                             // :262
+    // :263 warp_decode(f, kp_source = x_can, kp_driving = x_t)
+    TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_t, /*kp_s*/ x_can, nullptr, st));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }));
+    TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
+    float* dst = out_f32 ? out_f32 : e->img_a;
+    TRY(run_G(e, B, e->seg16, dst, st));
+    if (out_u8) TRY(e->run(1, st, [&] { return launch_pack_u8(dst, out_u8, B, 3, 512, 512, st); }));
+    return 0;
+}
+
+extern "C" int cs_profile_begin(cs_engine* e)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    e->prof = true; e->recs.clear(); e->evnext = 0; e->flops = 0;
+    return 0;
+}
+
+extern "C" int cs_profile_end(cs_engine* e, double ms[2], long counts[2], double* flops)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    CS_CHECK_HIP(hipDeviceSynchronize());
+    ms[0] = ms[1] = 0; counts[0] = counts[1] = 0;
+    for (auto& r : e->recs) {
+        float t = 0;
+        CS_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.fam] += t; counts[r.fam]++;
+    }
+    if (flops) *flops = e->flops;
+    e->prof = false; e->recs.clear(); e->evnext = 0;
+    return 0;
+}
+
+// ---- operator level
+extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
+{
+    ConvCall c;
+    memset(&c.p, 0, sizeof(c.p));
+    ConvParams& p = c.p;
+    p.in = (const half_t*)d->in; p.in_sN = d->in_sN; p.in_sD = d->in_sD; p.in_sH = d->in_sH; p.in_sW = d->in_sW;
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.nchunks = (d->Cin + 31) / 32; p.up_shift = d->up_shift;
+    p.KD = d->KD; p.KH = d->KH; p.KW = d->KW; p.PD = d->KD / 2; p.PH = d->KH / 2; p.PW = d->KW / 2;
+    p.wgt = (const half_t*)d->wgt; p.Cout_pad = d->Cout_pad; p.Cout = d->Cout;
+    p.bias = d->bias; p.bias2 = d->bias2; p.act0 = d->act0; p.slope0 = d->slope0;
+    p.res = td((void*)d->res, d->res_sN, d->res_sD, d->res_sH, d->res_sW); p.res_f32 = d->res_f32; p.res_shift = d->res_shift;
+    p.pixscale = d->pixscale; p.ps_stride = d->ps_stride ? d->ps_stride : 1;
+    p.out0 = td(d->out0, d->out0_sN, d->out0_sD, d->out0_sH, d->out0_sW); p.out0_f32 = d->out0_f32;
+    p.s2 = d->s2; p.t2 = d->t2; p.act1 = d->act1; p.slope1 = d->slope1;
+    p.out1 = td(d->out1, d->out1_sN, d->out1_sD, d->out1_sH, d->out1_sW);
+    p.stats = d->stats; p.stat_cnt_inv = d->stat_cnt_inv; p.eps = d->eps;
+    c.mode = d->mode;
+    c.cfg = d->cfg >= 0 ? d->cfg : pick_cfg(p.Cout_pad);
+    const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
+    set_tile(p, BM, d->tile_w ? d->tile_w : 16, d->tile_h ? d->tile_h : BM / 16);
+    return launch_conv(p, c.cfg, c.mode, (hipStream_t)stream);
+}
+
+extern "C" int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,
+                                   void* stream)
+{
+    return launch_grid_sample(in_hwdc, grid, out32, (half_t*)out16, N, D, H, W, (hipStream_t)stream);
+}
+
+extern "C" int cs_op_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, void* stream)
+{
+    return launch_chan_stats(x, is_f32, N, P, C, stats, (hipStream_t)stream);
+}

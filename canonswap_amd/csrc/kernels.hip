@@ -1,0 +1,684 @@
+// HBM-bound kernels of the CanonSwap generator path for gfx950: trilinear grid-sample of the
+// feature volume, the fused sparse-motion sampler, normalisation statistics / application, pooling,
+// layout conversion at the API boundary, and the per-identity weight modulation.
+// Each kernel cites the reference lines it replaces. Internal layouts:
+//   feature volumes  [N][H][W][D=16][C=32]   ("HWDC": the reference's view(bs, c*d, h, w) is free)
+//   dense-motion     [N][D][H][W][C]
+//   2D feature maps  [N][H][W][C]
+#include "common.h"
+
+#define LAUNCH_CHECK(name)                                                        \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) { cs_set_error(name ": %s", hipGetErrorString(_e)); return -1; } \
+    } while (0)
+
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+// first encoder layer: conv 3x3 3->64 + folded BN + ReLU (appearance_feature_extractor.py:22,39;
+// util.py:207-211). K = 27 is too small for MFMA: direct convolution, fp32 NCHW in, fp16 NHWC out.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_first_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                         const float* __restrict__ b, half_t* __restrict__ out, int N, int H, int W)
+{
+    __shared__ float ws[64 * 27 + 64];
+    for (int i = threadIdx.x; i < 64 * 27 + 64; i += 256) ws[i] = i < 64 * 27 ? w[i] : b[i - 64 * 27];
+    __syncthreads();
+    const long pix = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cg = threadIdx.x >> 6;  // 16 output channels per thread
+    if (pix >= (long)N * H * W) return;
+    const int x = pix % W, y = (pix / W) % H, n = pix / ((long)W * H);
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                in[c * 9 + ky * 3 + kx] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                                              ? img[(((long)n * 3 + c) * H + yy) * W + xx] : 0.f;
+            }
+    half_t o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int oc = cg * 16 + j;
+        float a = ws[64 * 27 + oc];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) a = fmaf(in[k], ws[oc * 27 + k], a);
+        o[j] = (half_t)fmaxf(a, 0.f);
+    }
+    uint4* dst = (uint4*)(out + pix * 64 + cg * 16);
+    dst[0] = *(uint4*)&o[0];
+    dst[1] = *(uint4*)&o[8];
+}
+
+int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(conv_first_kernel, dim3(cdiv((long)N * H * W, 64)), dim3(256), 0, st, img, w, b, out, N, H, W);
+    LAUNCH_CHECK("conv_first");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AvgPool over (H,W) 2x2 (nn.AvgPool2d(2) util.py:158,165; nn.AvgPool3d((1,2,2)) util.py:183,189)
+// in: contiguous [N][D][H][W][C] fp16; out: strided view (so it can land inside a concat buffer)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) avgpool_kernel(const half_t* __restrict__ in, int N, int D, int H, int W, int C, TDesc out)
+{
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * D * Ho * Wo * C8;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = i % C8; i /= C8;
+    const int x = i % Wo; i /= Wo;
+    const int y = i % Ho; i /= Ho;
+    const int d = i % D;
+    const int n = i / D;
+    const half_t* src = in + ((((long)n * D + d) * H + 2 * y) * W + 2 * x) * C + c8 * 8;
+    const h8_t a = *(const h8_t*)src, b = *(const h8_t*)(src + C), c = *(const h8_t*)(src + (long)W * C),
+               e = *(const h8_t*)(src + (long)W * C + C);
+    h8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)a[j] + (float)b[j] + (float)c[j] + (float)e[j]) * 0.25f);
+    *(h8_t*)((half_t*)out.p + (long)n * out.sN + (long)d * out.sD + (long)y * out.sH + (long)x * out.sW + c8 * 8) = o;
+}
+
+int launch_avgpool(const half_t* in, int N, int D, int H, int W, int C, TDesc out, hipStream_t st)
+{
+    const long total = (long)N * D * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, in, N, D, H, W, C, out);
+    LAUNCH_CHECK("avgpool");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense motion front end
+// ------------------------------------------------------------------------------------------------
+// compress 1x1x1 conv 32->4 + BN3d(eval, folded) + ReLU  (dense_motion.py:70-72)
+// in: fp32 HWDC feature; out: fp16 [N][D][H][W][4]
+__global__ void __launch_bounds__(256) dm_compress_kernel(const float* __restrict__ f, const float* __restrict__ w,
+                                                          const float* __restrict__ b, half_t* __restrict__ comp, int N, int D, int H, int W)
+{
+    __shared__ float ws[4 * 32 + 4];
+    if (threadIdx.x < 132) ws[threadIdx.x] = threadIdx.x < 128 ? w[threadIdx.x] : b[threadIdx.x - 128];
+    __syncthreads();
+    long i = (long)blockIdx.x * 256 + threadIdx.x;  // over HWDC voxel order (coalesced reads)
+    const long total = (long)N * H * W * D;
+    if (i >= total) return;
+    const float4* src = (const float4*)(f + i * 32);
+    float a0 = ws[128], a1 = ws[129], a2 = ws[130], a3 = ws[131];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = src[j];
+        const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a0 = fmaf(x[r], ws[0 * 32 + j * 4 + r], a0);
+            a1 = fmaf(x[r], ws[1 * 32 + j * 4 + r], a1);
+            a2 = fmaf(x[r], ws[2 * 32 + j * 4 + r], a2);
+            a3 = fmaf(x[r], ws[3 * 32 + j * 4 + r], a3);
+        }
+    }
+    const int d = i % D; long r = i / D;
+    const int x = r % W; r /= W;
+    const int y = r % H;
+    const int n = r / H;
+    h4_t o;
+    o[0] = (half_t)fmaxf(a0, 0.f); o[1] = (half_t)fmaxf(a1, 0.f); o[2] = (half_t)fmaxf(a2, 0.f); o[3] = (half_t)fmaxf(a3, 0.f);
+    *(h4_t*)(comp + ((((long)n * D + d) * H + y) * W + x) * 4) = o;
+}
+
+int launch_dm_compress(const float* f, const float* w, const float* b, half_t* comp, int N, int D, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(dm_compress_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, f, w, b, comp, N, D, H, W);
+    LAUNCH_CHECK("dm_compress");
+    return 0;
+}
+
+__device__ __forceinline__ float grid_coord(int i, int n) { return 2.f * ((float)i / (float)(n - 1)) - 1.f; }  // util.py:48-50
+
+// Fused create_sparse_motions + create_deformed_feature + create_heatmap_representations + concat
+// (dense_motion.py:29-65,77-84). The 22x(16x64x64x3) grid tensor is never materialised: each thread
+// rebuilds its sampling point from the key-points. Output: 112 fp16 channels per voxel
+// (channel k*5 = heat-map_k, k*5+1..4 = deformed feature_k, 110/111 = zero pad) at pixel stride `ostride`.
+__global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict__ comp, const float* __restrict__ kp_d,
+                                                        const float* __restrict__ kp_s, half_t* __restrict__ out, int ostride,
+                                                        int N, int D, int H, int W)
+{
+    const long total = (long)N * D * H * W * 23;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = i % 23; long v = i / 23;
+    half_t* o = out + v * ostride + k * 5;
+    if (k == 22) { o[0] = (half_t)0.f; o[1] = (half_t)0.f; return; }
+    const int x = v % W; long r = v / W;
+    const int y = r % H; r /= H;
+    const int d = r % D;
+    const int n = r / D;
+    const float gx = grid_coord(x, W), gy = grid_coord(y, H), gz = grid_coord(d, D);
+    float sx = gx, sy = gy, sz = gz, heat = 0.f;
+    if (k > 0) {
+        const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
+        const float* ps = kp_s + ((long)n * 21 + (k - 1)) * 3;
+        sx = (gx - pd[0]) + ps[0]; sy = (gy - pd[1]) + ps[1]; sz = (gz - pd[2]) + ps[2];
+        const float dd = (gx - pd[0]) * (gx - pd[0]) + (gy - pd[1]) * (gy - pd[1]) + (gz - pd[2]) * (gz - pd[2]);
+        const float ds = (gx - ps[0]) * (gx - ps[0]) + (gy - ps[1]) * (gy - ps[1]) + (gz - ps[2]) * (gz - ps[2]);
+        heat = __expf(-0.5f * dd / 0.01f) - __expf(-0.5f * ds / 0.01f);   // util.py:36 kp_variance = 0.01
+    }
+    // F.grid_sample(..., align_corners=False), trilinear, zeros padding (dense_motion.py:50)
+    const float ix = ((sx + 1.f) * W - 1.f) * 0.5f, iy = ((sy + 1.f) * H - 1.f) * 0.5f, iz = ((sz + 1.f) * D - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const half_t* base = comp + (long)n * D * H * W * 4;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
+                if ((unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D) {
+                    const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                    const h4_t c = *(const h4_t*)(base + (((long)zc * H + yc) * W + xc) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = fmaf(wgt, (float)c[j], a[j]);
+                }
+            }
+    o[0] = (half_t)heat;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[1 + j] = (half_t)a[j];
+}
+
+int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, half_t* out, int out_stride, int N, int D, int H,
+                     int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(dm_sparse_kernel, dim3(cdiv((long)N * D * H * W * 23, 256)), dim3(256), 0, st, comp, kp_d, kp_s, out,
+                       out_stride, N, D, H, W);
+    LAUNCH_CHECK("dm_sparse");
+    return 0;
+}
+
+// softmax over the 22 mask logits + deformation = sum_k mask_k * sparse_motion_k (dense_motion.py:89-94)
+// logits: fp32 [voxel][lstride]; deformation out: fp32 [N][D][H][W][3]; optional mask out [N][22][D][H][W].
+__global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict__ logits, int lstride, const float* __restrict__ kp_d,
+                                                         const float* __restrict__ kp_s, float* __restrict__ deform,
+                                                         float* __restrict__ mask_out, int N, int D, int H, int W)
+{
+    const long total = (long)N * D * H * W;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= total) return;
+    const int x = v % W; long r = v / W;
+    const int y = r % H; r /= H;
+    const int d = r % D;
+    const int n = r / D;
+    float l[22];
+    const float4* src = (const float4*)(logits + v * lstride);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { const float4 q = src[j]; l[j * 4] = q.x; l[j * 4 + 1] = q.y; l[j * 4 + 2] = q.z; l[j * 4 + 3] = q.w; }
+    { const float4 q = src[5]; l[20] = q.x; l[21] = q.y; }
+    float mx = l[0];
+#pragma unroll
+    for (int k = 1; k < 22; ++k) mx = fmaxf(mx, l[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 22; ++k) { l[k] = __expf(l[k] - mx); sum += l[k]; }
+    const float inv = 1.f / sum;
+    const float gx = grid_coord(x, W), gy = grid_coord(y, H), gz = grid_coord(d, D);
+    float ox = gx * (l[0] * inv), oy = gy * (l[0] * inv), oz = gz * (l[0] * inv);
+#pragma unroll
+    for (int k = 1; k < 22; ++k) {
+        const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
+        const float* ps = kp_s + ((long)n * 21 + (k - 1)) * 3;
+        const float m = l[k] * inv;
+        ox = fmaf(m, (gx - pd[0]) + ps[0], ox);
+        oy = fmaf(m, (gy - pd[1]) + ps[1], oy);
+        oz = fmaf(m, (gz - pd[2]) + ps[2], oz);
+    }
+    float* o = deform + v * 3;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+    if (mask_out) {
+        const long dhw = (long)D * H * W, sp = ((long)d * H + y) * W + x;
+#pragma unroll
+        for (int k = 0; k < 22; ++k) mask_out[((long)n * 22 + k) * dhw + sp] = l[k] * inv;
+    }
+}
+
+int launch_dm_softmax(const float* logits, int lstride, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
+                      int N, int D, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(dm_softmax_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, logits, lstride, kp_d, kp_s,
+                       deform, mask_out, N, D, H, W);
+    LAUNCH_CHECK("dm_softmax");
+    return 0;
+}
+
+// occlusion map: conv2d 7x7 over the (c,d)-flattened prediction -> 1 channel, sigmoid
+// (dense_motion.py:25,98-102). N_out = 1, so this is a reduction, not MFMA work.
+// pred: fp16 [N][D][H][W][C]; w: fp16 [D][7][7][C]; occ: fp32 [N][H][W].
+// workgroup = 16 output columns x 16 depth slices; LDS reduction over depth.
+__global__ void __launch_bounds__(256) dm_occlusion_kernel(const half_t* __restrict__ pred, int C, const half_t* __restrict__ w,
+                                                           float bias, float* __restrict__ occ, int N, int D, int H, int W)
+{
+    __shared__ float red[256];
+    const int xl = threadIdx.x & 15, d = threadIdx.x >> 4;
+    const int xt = blockIdx.x % (W / 16);
+    const int y = (blockIdx.x / (W / 16)) % H;
+    const int n = blockIdx.x / ((W / 16) * H);
+    const int x = xt * 16 + xl;
+    const int C8 = C >> 3;
+    float acc = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        const int yy = y + ky - 3;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 7; ++kx) {
+            const int xx = x + kx - 3;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const h8_t* a = (const h8_t*)(pred + ((((long)n * D + d) * H + yy) * W + xx) * C);
+            const h8_t* b = (const h8_t*)(w + ((long)(d * 7 + ky) * 7 + kx) * C);
+            for (int c = 0; c < C8; ++c) {
+                const h8_t av = a[c], bv = b[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = fmaf((float)av[j], (float)bv[j], acc);
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (d == 0) {
+        float s = bias;
+        for (int j = 0; j < D; ++j) s += red[j * 16 + xl];
+        occ[((long)n * H + y) * W + x] = 1.f / (1.f + __expf(-s));
+    }
+}
+
+int launch_dm_occlusion(const half_t* pred, int C, const half_t* w, float bias, float* occ, int N, int D, int H, int W, hipStream_t st)
+{
+    if (D != 16 || W % 16) { cs_set_error("dm_occlusion: needs D == 16 and W %% 16 == 0"); return -1; }
+    hipLaunchKernelGGL(dm_occlusion_kernel, dim3((unsigned)((long)N * H * (W / 16))), dim3(256), 0, st, pred, C, w, bias, occ, N, D, H, W);
+    LAUNCH_CHECK("dm_occlusion");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature warp: F.grid_sample(feature, deformation, align_corners=False) (warping_network.py:46-47)
+// in/out: fp32 HWDC [N][H][W][D][32]; grid: fp32 [N][D][H][W][3] (x,y,z). 8 lanes cover one voxel's
+// 32 channels with float4 accesses, so every tap is one 128-byte coalesced read.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restrict__ in, const float* __restrict__ grid,
+                                                          float* __restrict__ out32, half_t* __restrict__ out16, int N, int D, int H, int W)
+{
+    const long total = (long)N * H * W * D * 8;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cg = i & 7; long v = i >> 3;     // v: voxel index in HWDC order
+    const int d = v % D; long r = v / D;
+    const int x = r % W; r /= W;
+    const int y = r % H;
+    const int n = r / H;
+    const float* g = grid + ((((long)n * D + d) * H + y) * W + x) * 3;
+    const float ix = ((g[0] + 1.f) * W - 1.f) * 0.5f, iy = ((g[1] + 1.f) * H - 1.f) * 0.5f, iz = ((g[2] + 1.f) * D - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* base = in + (long)n * H * W * D * 32 + cg * 4;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
+                if ((unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D) {
+                    const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                    const float4 c = *(const float4*)(base + (((long)yc * W + xc) * D + zc) * 32);
+                    a[0] = fmaf(wgt, c.x, a[0]); a[1] = fmaf(wgt, c.y, a[1]); a[2] = fmaf(wgt, c.z, a[2]); a[3] = fmaf(wgt, c.w, a[3]);
+                }
+            }
+    if (out32) *(float4*)(out32 + v * 32 + cg * 4) = make_float4(a[0], a[1], a[2], a[3]);
+    if (out16) {
+        h4_t o; o[0] = (half_t)a[0]; o[1] = (half_t)a[1]; o[2] = (half_t)a[2]; o[3] = (half_t)a[3];
+        *(h4_t*)(out16 + v * 32 + cg * 4) = o;
+    }
+}
+
+int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(grid_sample_kernel, dim3(cdiv((long)N * D * H * W * 8, 256)), dim3(256), 0, st, in, grid, out32, out16, N, D, H, W);
+    LAUNCH_CHECK("grid_sample");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-(n, channel) sum / sum of squares over P positions of a [N][P][C] tensor
+// (InstanceNorm2d util.py:286,296; GroupNorm(32,32) util.py:521-523). stats must be zeroed first.
+// ------------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict__ xin, long P, int C, int ppb, float* __restrict__ stats)
+{
+    __shared__ float red[256 * 8];
+    const int G = C >> 2;            // channel groups of 4
+    const int g = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
+    const int n = blockIdx.y;
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < P ? p0 + ppb : P;
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (long p = p0 + pl; p < p1; p += PL) {
+        float v[4];
+        if (F32) {
+            const float4 q = *(const float4*)((const float*)xin + ((long)n * P + p) * C + g * 4);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            const h4_t q = *(const h4_t*)((const half_t*)xin + ((long)n * P + p) * C + g * 4);
+            v[0] = (float)q[0]; v[1] = (float)q[1]; v[2] = (float)q[2]; v[3] = (float)q[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[r] += v[r]; ss[r] = fmaf(v[r], v[r], ss[r]); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[threadIdx.x * 8 + r] = s[r]; red[threadIdx.x * 8 + 4 + r] = ss[r]; }
+    __syncthreads();
+    if (pl == 0) {
+        for (int j = 1; j < PL; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] += red[(j * G + g) * 8 + r]; ss[r] += red[(j * G + g) * 8 + 4 + r]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            atomicAdd(stats + ((long)n * C + g * 4 + r) * 2, s[r]);
+            atomicAdd(stats + ((long)n * C + g * 4 + r) * 2 + 1, ss[r]);
+        }
+    }
+}
+
+int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, hipStream_t st)
+{
+    const int G = C / 4;
+    if (C % 4 || G > 256 || 256 % G) { cs_set_error("chan_stats: unsupported C=%d", C); return -1; }
+    const int PL = 256 / G;
+    const int ppb = P <= 16384 ? PL * 16 : PL * 32;   // 16-32 positions per thread, many workgroups
+    dim3 grid(cdiv(P, ppb), (unsigned)N);
+    if (is_f32) hipLaunchKernelGGL(chan_stats_kernel<true>, grid, dim3(256), 0, st, x, P, C, ppb, stats);
+    else hipLaunchKernelGGL(chan_stats_kernel<false>, grid, dim3(256), 0, st, x, P, C, ppb, stats);
+    LAUNCH_CHECK("chan_stats");
+    return 0;
+}
+
+__device__ __forceinline__ float act_f(float v, int act, float slope)
+{
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+// GroupNorm(32,32) apply + optional residual + LeakyReLU (util.py:531-540), on fp32 HWDC volumes.
+// out32 = lrelu(gn(y) [+ res]); out16 = act2(out32 * s2[i % period2] + t2[i % period2]) (next conv's input).
+__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ y, const float* __restrict__ stats, float cnt_inv,
+                                                       float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ res, float slope, float* __restrict__ out32,
+                                                       half_t* __restrict__ out16, const float* __restrict__ s2,
+                                                       const float* __restrict__ t2, int period2, int act2, float slope2, long per_n,
+                                                       long total4)
+{
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const long i = i4 * 4;
+    const int n = i / per_n;
+    const int c = i & 31;
+    const float4 q = *(const float4*)(y + i);
+    float v[4] = {q.x, q.y, q.z, q.w};
+    float rr[4] = {0, 0, 0, 0};
+    if (res) { const float4 t = *(const float4*)(res + i); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+    h4_t o16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float* st = stats + ((long)n * 32 + c + r) * 2;
+        const float mean = st[0] * cnt_inv;
+        const float var = fmaxf(st[1] * cnt_inv - mean * mean, 0.f);
+        float a = (v[r] - mean) * rsqrtf(var + eps) * gamma[c + r] + beta[c + r] + rr[r];
+        a = a > 0.f ? a : a * slope;
+        v[r] = a;
+        if (s2) { const int j = (int)((i + r) % period2); a = a * s2[j] + t2[j]; }
+        o16[r] = (half_t)act_f(a, act2, slope2);
+    }
+    if (out32) *(float4*)(out32 + i) = make_float4(v[0], v[1], v[2], v[3]);
+    if (out16) *(h4_t*)(out16 + i) = o16;
+}
+
+int launch_norm_act(const float* y, const float* stats, float cnt_inv, float eps, const float* gamma, const float* beta,
+                    const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
+                    int act2, float slope2, int N, long per_n, hipStream_t st)
+{
+    const long total4 = (long)N * per_n / 4;
+    hipLaunchKernelGGL(norm_act_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, y, stats, cnt_inv, eps, gamma, beta, res, slope,
+                       out32, out16, s2, t2, period2, act2, slope2, per_n, total4);
+    LAUNCH_CHECK("norm_act");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// API-boundary layout conversion (the reference passes fp32 NCDHW / NCHW tensors between stages)
+// ------------------------------------------------------------------------------------------------
+// fp32 NCDHW [N][C][D][H][W] -> fp32 HWDC (+ optional fp16 pre-activation copy act2(x*s2[c]+t2[c]))
+__global__ void __launch_bounds__(256) ncdhw_to_hwdc_kernel(const float* __restrict__ in, float* __restrict__ out32,
+                                                            half_t* __restrict__ out16, const float* __restrict__ s2,
+                                                            const float* __restrict__ t2, int act2, float slope2, int N, int C, int D,
+                                                            int H, int W)
+{
+    // tile: one (n, d, y) row: transpose [C][W] -> [W][C] through LDS
+    __shared__ float tile[32][65];
+    const int y = blockIdx.x % H, d = (blockIdx.x / H) % D, n = blockIdx.x / (H * D);
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        for (int j = threadIdx.x; j < C * 64; j += 256) {
+            const int c = j / 64, x = j % 64;
+            if (x0 + x < W) tile[c][x] = in[((((long)n * C + c) * D + d) * H + y) * W + x0 + x];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < C * 64; j += 256) {
+            const int x = j / C, c = j % C;
+            if (x0 + x < W) {
+                const float v = tile[c][x];
+                const long o = ((((long)n * H + y) * W + x0 + x) * D + d) * C + c;
+                if (out32) out32[o] = v;
+                if (out16) out16[o] = (half_t)act_f(s2 ? v * s2[c] + t2[c] : v, act2, slope2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,
+                         int N, int C, int D, int H, int W, hipStream_t st)
+{
+    if (C != 32) { cs_set_error("ncdhw_to_hwdc: C must be 32"); return -1; }
+    hipLaunchKernelGGL(ncdhw_to_hwdc_kernel, dim3((unsigned)((long)N * D * H)), dim3(256), 0, st, in, out32, out16, s2, t2, act2, slope2,
+                       N, C, D, H, W);
+    LAUNCH_CHECK("ncdhw_to_hwdc");
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) hwdc_to_ncdhw_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int D,
+                                                            int H, int W)
+{
+    __shared__ float tile[32][65];
+    const int y = blockIdx.x % H, d = (blockIdx.x / H) % D, n = blockIdx.x / (H * D);
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        for (int j = threadIdx.x; j < C * 64; j += 256) {
+            const int x = j / C, c = j % C;
+            if (x0 + x < W) tile[c][x] = in[((((long)n * H + y) * W + x0 + x) * D + d) * C + c];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < C * 64; j += 256) {
+            const int c = j / 64, x = j % 64;
+            if (x0 + x < W) out[((((long)n * C + c) * D + d) * H + y) * W + x0 + x] = tile[c][x];
+        }
+        __syncthreads();
+    }
+}
+
+int launch_hwdc_to_ncdhw(const float* in, float* out, int N, int C, int D, int H, int W, hipStream_t st)
+{
+    if (C != 32) { cs_set_error("hwdc_to_ncdhw: C must be 32"); return -1; }
+    hipLaunchKernelGGL(hwdc_to_ncdhw_kernel, dim3((unsigned)((long)N * D * H)), dim3(256), 0, st, in, out, N, C, D, H, W);
+    LAUNCH_CHECK("hwdc_to_ncdhw");
+    return 0;
+}
+
+// fp32 NCHW -> fp16 NHWC and back (HW = H*W, multiple of 64; C multiple of 32)
+__global__ void __launch_bounds__(256) nchw_to_nhwc16_kernel(const float* __restrict__ in, half_t* __restrict__ out, int N, int C, int HW)
+{
+    __shared__ float tile[32][65];
+    const int pt = blockIdx.x % (HW / 64), ct = (blockIdx.x / (HW / 64)) % (C / 32), n = blockIdx.x / ((HW / 64) * (C / 32));
+    for (int j = threadIdx.x; j < 32 * 64; j += 256) {
+        const int c = j / 64, p = j % 64;
+        tile[c][p] = in[((long)n * C + ct * 32 + c) * HW + pt * 64 + p];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 32 * 64; j += 256) {
+        const int p = j / 32, c = j % 32;
+        out[((long)n * HW + pt * 64 + p) * C + ct * 32 + c] = (half_t)tile[c][p];
+    }
+}
+
+int launch_nchw_to_nhwc16(const float* in, half_t* out, int N, int C, int HW, hipStream_t st)
+{
+    if (C % 32 || HW % 64) { cs_set_error("nchw_to_nhwc16: bad shape"); return -1; }
+    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3((unsigned)((long)N * (C / 32) * (HW / 64))), dim3(256), 0, st, in, out, N, C, HW);
+    LAUNCH_CHECK("nchw_to_nhwc16");
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) nhwc16_to_nchw_kernel(const half_t* __restrict__ in, float* __restrict__ out, int N, int C, int HW)
+{
+    __shared__ float tile[32][65];
+    const int pt = blockIdx.x % (HW / 64), ct = (blockIdx.x / (HW / 64)) % (C / 32), n = blockIdx.x / ((HW / 64) * (C / 32));
+    for (int j = threadIdx.x; j < 32 * 64; j += 256) {
+        const int p = j / 32, c = j % 32;
+        tile[c][p] = (float)in[((long)n * HW + pt * 64 + p) * C + ct * 32 + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 32 * 64; j += 256) {
+        const int c = j / 64, p = j % 64;
+        out[((long)n * C + ct * 32 + c) * HW + pt * 64 + p] = tile[c][p];
+    }
+}
+
+int launch_nhwc16_to_nchw(const half_t* in, float* out, int N, int C, int HW, hipStream_t st)
+{
+    if (C % 32 || HW % 64) { cs_set_error("nhwc16_to_nchw: bad shape"); return -1; }
+    hipLaunchKernelGGL(nhwc16_to_nchw_kernel, dim3((unsigned)((long)N * (C / 32) * (HW / 64))), dim3(256), 0, st, in, out, N, C, HW);
+    LAUNCH_CHECK("nhwc16_to_nchw");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-identity precompute for T (adaptive_modulate.py:148-155), once per source identity
+// ------------------------------------------------------------------------------------------------
+// fc: per layer [W1 512x512][b1 512][W2 512x512][b2 512] fp32; style out [nlayers][512] (reference channel order)
+__global__ void __launch_bounds__(512) t_style_kernel(const float* __restrict__ id, const float* __restrict__ fc, float* __restrict__ style)
+{
+    __shared__ float v[512], hbuf[512];
+    const int j = threadIdx.x;
+    const float* L = fc + (long)blockIdx.x * (2 * (512 * 512 + 512));
+    v[j] = id[j];
+    __syncthreads();
+    float a = L[512 * 512 + j];
+    for (int i = 0; i < 512; ++i) a = fmaf(L[(long)j * 512 + i], v[i], a);
+    hbuf[j] = a > 0.f ? a : 0.2f * a;
+    __syncthreads();
+    const float* L2 = L + 512 * 512 + 512;
+    float b = L2[512 * 512 + j];
+    for (int i = 0; i < 512; ++i) b = fmaf(L2[(long)j * 512 + i], hbuf[i], b);
+    style[(long)blockIdx.x * 512 + j] = b;
+}
+
+int launch_t_style(const float* id, const float* fc, float* style, int nlayers, hipStream_t st)
+{
+    hipLaunchKernelGGL(t_style_kernel, dim3(nlayers), dim3(512), 0, st, id, fc, style);
+    LAUNCH_CHECK("t_style");
+    return 0;
+}
+
+// wraw: fp32 [512 o][9 taps][512 i] in MEMORY channel order, style already permuted to memory order.
+// Writes the demodulated fp16 rows into the fused packed weight [kstep = chunk*9+tap][1024][32],
+// packed row of memory out-channel o (kind 1 = modulated) = ((o/16)*2 + 1)*16 + o%16.
+__global__ void __launch_bounds__(256) t_modulate_kernel(const float* __restrict__ wraw, const float* __restrict__ style,
+                                                         half_t* __restrict__ packed)
+{
+    __shared__ float red[256];
+    const int o = blockIdx.x;
+    const float* src = wraw + (long)o * 9 * 512;
+    float wv[18];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        const int e = threadIdx.x + 256 * j;     // e = tap*512 + i
+        const float m = src[e] * style[e & 511];
+        wv[j] = m;
+        ss = fmaf(m, m, ss);
+    }
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float demod = rsqrtf(red[0] + 1e-8f);
+    const int prow = ((o >> 4) * 2 + 1) * 16 + (o & 15);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        const int e = threadIdx.x + 256 * j;
+        const int tap = e >> 9, i = e & 511;
+        packed[((long)((i >> 5) * 9 + tap) * 1024 + prow) * 32 + (i & 31)] = (half_t)(wv[j] * demod);
+    }
+}
+
+int launch_t_modulate(const float* wraw, const float* style, half_t* packed, int layer, hipStream_t st)
+{
+    (void)layer;
+    hipLaunchKernelGGL(t_modulate_kernel, dim3(512), dim3(256), 0, st, wraw, style, packed);
+    LAUNCH_CHECK("t_modulate");
+    return 0;
+}
+
+// parse_output on device (can_swap_e2e.py:314-322): NCHW fp32 -> NHWC u8, clip, *255, truncate
+__global__ void __launch_bounds__(256) pack_u8_kernel(const float* __restrict__ img, uint8_t* __restrict__ out, int N, int C, int H, int W)
+{
+    const long total = (long)N * H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / ((long)H * W), p = i % ((long)H * W);
+    for (int c = 0; c < C; ++c) {
+        float v = img[(n * C + c) * (long)H * W + p];
+        v = fminf(fmaxf(v, 0.f), 1.f) * 255.f;
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        out[i * C + c] = (uint8_t)v;
+    }
+}
+
+int launch_pack_u8(const float* img, uint8_t* out, int N, int C, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_u8_kernel, dim3(cdiv((long)N * H * W, 256)), dim3(256), 0, st, img, out, N, C, H, W);
+    LAUNCH_CHECK("pack_u8");
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) lrelu16_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, long n8, float slope)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    h8_t v = ((const h8_t*)in)[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; v[j] = (half_t)(f > 0.f ? f : f * slope); }
+    ((h8_t*)out)[i] = v;
+}
+
+int launch_lrelu16(const half_t* in, half_t* out, long n, float slope, hipStream_t st)
+{
+    hipLaunchKernelGGL(lrelu16_kernel, dim3(cdiv(n / 8, 256)), dim3(256), 0, st, in, out, n / 8, slope);
+    LAUNCH_CHECK("lrelu16");
+    return 0;
+}

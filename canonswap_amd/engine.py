@@ -1,0 +1,173 @@
+"""Thin Python handle over the C ABI (include/canonswap_hip.h).
+
+PyTorch is plumbing here: it owns the caller-visible device tensors and the HIP stream; every operation on
+the generator path is a HIP kernel launched by libcanonswap_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, pack
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class Engine:
+    """One engine per device; not thread-safe (same contract as the C ABI)."""
+
+    def __init__(self, device_id: int = 0, max_batch: int = 8):
+        if not torch.cuda.is_available():
+            raise RuntimeError("canonswap_amd.Engine needs a ROCm device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(f"cuda:{device_id}")
+        self.max_batch = max_batch
+        h = C.c_void_p()
+        _lib.check(self.lib.cs_create(device_id, max_batch, C.byref(h)), "cs_create")
+        self.h = h
+        self._id_key = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def load_state_dicts(self, state_dicts: dict):
+        """Ingest the reference's six state-dicts (src/can_swap_e2e.py:87-100 key layout)."""
+        blobs = pack.build_blobs(state_dicts)
+        for name, arr in blobs.items():
+            arr = np.ascontiguousarray(arr)
+            _lib.check(self.lib.cs_upload(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.nbytes), f"cs_upload({name})")
+        _lib.check(self.lib.cs_finalize_weights(self.h), "cs_finalize_weights")
+        self._id_key = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _in(self, t, shape_tail=None):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("expected a torch.Tensor")
+        if t.device != self.device:
+            t = t.to(self.device)
+        t = t.contiguous().float()
+        if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+            raise ValueError(f"expected shape (B, {', '.join(map(str, shape_tail))}), got {tuple(t.shape)}")
+        if t.shape[0] < 1 or t.shape[0] > self.max_batch:
+            raise ValueError(f"batch {t.shape[0]} outside [1, {self.max_batch}]")
+        return t
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def set_identity(self, source_id: torch.Tensor, slot: int = 0):
+        """Per-identity precompute of T's modulated weights (adaptive_modulate.py:148-155). source_id: (1,512) or (512,)."""
+        sid = source_id.detach().to(self.device).float().reshape(-1, 512)
+        if sid.shape[0] != 1 and not bool((sid == sid[:1]).all()):
+            raise ValueError("one identity per slot: all rows of source_id must be equal")
+        sid = sid[0].contiguous()
+        _lib.check(self.lib.cs_set_identity(self.h, slot, _ptr(sid), self._stream()), "cs_set_identity")
+        self._keep = sid
+
+    def ensure_identity(self, source_id: torch.Tensor):
+        key = (source_id.data_ptr(), source_id._version, tuple(source_id.shape))
+        if key != self._id_key:
+            self.set_identity(source_id)
+            self._id_key = key
+
+    # ---------------------------------------------------------------- stages
+    def extract_feature_3d(self, img):
+        img = self._in(img, (3, 256, 256))
+        out = self._new(img.shape[0], 32, 16, 64, 64)
+        _lib.check(self.lib.cs_extract_feature_3d(self.h, img.shape[0], _ptr(img), _ptr(out), self._stream()), "cs_extract_feature_3d")
+        return out
+
+    def warp(self, f, kp_source, kp_driving):
+        f = self._in(f, (32, 16, 64, 64)); ks = self._in(kp_source, (21, 3)); kd = self._in(kp_driving, (21, 3))
+        B = f.shape[0]
+        out, occ = self._new(B, 32, 16, 64, 64), self._new(B, 1, 64, 64)
+        _lib.check(self.lib.cs_warp(self.h, B, _ptr(f), _ptr(ks), _ptr(kd), _ptr(out), _ptr(occ), self._stream()), "cs_warp")
+        return out, occ
+
+    def warp_out(self, f, occ=None):
+        f = self._in(f, (32, 16, 64, 64))
+        B = f.shape[0]
+        occ = None if occ is None else self._in(occ, (1, 64, 64))
+        seg = self._new(B, 256, 64, 64)
+        _lib.check(self.lib.cs_warp_out(self.h, B, _ptr(f), _ptr(occ), _ptr(seg), self._stream()), "cs_warp_out")
+        return seg
+
+    def swap(self, f, source_id=None):
+        if source_id is not None:
+            self.ensure_identity(source_id)
+        f = self._in(f, (32, 16, 64, 64))
+        out = self._new(*f.shape)
+        _lib.check(self.lib.cs_swap(self.h, 0, f.shape[0], _ptr(f), _ptr(out), self._stream()), "cs_swap")
+        return out
+
+    def refine(self, f):
+        f = self._in(f, (32, 16, 64, 64))
+        out = self._new(*f.shape)
+        _lib.check(self.lib.cs_refine(self.h, f.shape[0], _ptr(f), _ptr(out), self._stream()), "cs_refine")
+        return out
+
+    def warp_forward(self, f, kp_driving, kp_source):
+        f = self._in(f, (32, 16, 64, 64)); kd = self._in(kp_driving, (21, 3)); ks = self._in(kp_source, (21, 3))
+        B = f.shape[0]
+        occ, deform, seg = self._new(B, 1, 64, 64), self._new(B, 16, 64, 64, 3), self._new(B, 256, 64, 64)
+        _lib.check(self.lib.cs_warp_forward(self.h, B, _ptr(f), _ptr(kd), _ptr(ks), _ptr(occ), _ptr(deform), _ptr(seg),
+                                            self._stream()), "cs_warp_forward")
+        return {"occlusion_map": occ, "deformation": deform, "out": seg}
+
+    def spade_decode(self, seg):
+        seg = self._in(seg, (256, 64, 64))
+        img = self._new(seg.shape[0], 3, 512, 512)
+        _lib.check(self.lib.cs_spade_decode(self.h, seg.shape[0], _ptr(seg), _ptr(img), self._stream()), "cs_spade_decode")
+        return img
+
+    def pack_u8(self, img):
+        img = self._in(img)
+        B, _, H, W = img.shape
+        out = self._new(B, H, W, 3, dtype=torch.uint8)
+        _lib.check(self.lib.cs_pack_u8(self.h, B, _ptr(img), _ptr(out), H, W, self._stream()), "cs_pack_u8")
+        return out
+
+    def swap_frames(self, img, x_t, x_can, source_id=None, want_f32=True, want_u8=False, debug=False,
+                    out_f32=None, out_u8=None):
+        """Whole loop body of can_swap_pipeline_e2e.py:242-263 for B frames, on device."""
+        if source_id is not None:
+            self.ensure_identity(source_id)
+        img = self._in(img, (3, 256, 256)); x_t = self._in(x_t, (21, 3)); x_can = self._in(x_can, (21, 3))
+        B = img.shape[0]
+        if want_f32 and out_f32 is None:
+            out_f32 = self._new(B, 3, 512, 512)
+        if want_u8 and out_u8 is None:
+            out_u8 = self._new(B, 512, 512, 3, dtype=torch.uint8)
+        rec = self._new(B, 3, 512, 512) if debug else None
+        swp = self._new(B, 3, 512, 512) if debug else None
+        _lib.check(self.lib.cs_swap_frames(self.h, 0, B, _ptr(img), _ptr(x_t), _ptr(x_can), _ptr(out_f32), _ptr(out_u8),
+                                           _ptr(rec), _ptr(swp), self._stream()), "cs_swap_frames")
+        res = {"out": out_f32, "out_u8": out_u8}
+        if debug:
+            res.update(rec_can=rec, swap_can=swp)
+        return res
+
+    # ---------------------------------------------------------------- measurement
+    def profile_begin(self):
+        _lib.check(self.lib.cs_profile_begin(self.h), "cs_profile_begin")
+
+    def profile_end(self):
+        ms, cnt, fl = (C.c_double * 2)(), (C.c_long * 2)(), C.c_double()
+        _lib.check(self.lib.cs_profile_end(self.h, ms, cnt, C.byref(fl)), "cs_profile_end")
+        return {"conv_ms": ms[0], "other_ms": ms[1], "conv_launches": cnt[0], "other_launches": cnt[1], "conv_flops": fl.value}

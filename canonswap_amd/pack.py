@@ -1,0 +1,239 @@
+"""Load-time weight transformation: reference state-dicts -> blobs the gfx950 engine consumes.
+
+Replaces ``can_swapper.load_cpk`` (src/can_swap_e2e.py:87-100): the same six state-dicts (same key names)
+are ingested; eval-mode BatchNorm and the legacy spectral-norm parametrisation are folded into the
+convolution weights, channels are reordered for the engine's channels-last layouts, and every
+convolution is packed into the K-step order of ``conv_igemm`` (csrc/conv_igemm.hip):
+
+    packed[kstep][row][kk] (fp16),  kstep = ((chunk*KD + kd)*KH + kh)*KW + kw,  in-channel = chunk*32 + kk
+
+Feature volumes live as [N][H][W][D=16][C=32] on the device, so the reference's 512-channel 2-D view
+(channel j = c*16 + d, e.g. warping_network.py:66) is the memory channel jm = d*32 + c.  ``MEM2REF[jm] = j``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS_BN = 1e-5
+MEM2REF = np.array([c * 16 + d for d in range(16) for c in range(32)], dtype=np.int64)
+
+
+def bn_affine(sd, p):
+    """Eval BatchNorm as y = x*s + t (running statistics, eps 1e-5)."""
+    s = sd[p + ".weight"].astype(np.float64) / np.sqrt(sd[p + ".running_var"].astype(np.float64) + EPS_BN)
+    t = sd[p + ".bias"].astype(np.float64) - sd[p + ".running_mean"].astype(np.float64) * s
+    return s, t
+
+
+def fold_conv_bn(w, b, s, t):
+    """conv followed by y*s+t  ->  conv with w*s[o], b*s+t."""
+    w = w.astype(np.float64) * s.reshape((-1,) + (1,) * (w.ndim - 1))
+    b = (np.zeros(w.shape[0]) if b is None else b.astype(np.float64)) * s + t
+    return w, b
+
+
+def spectral_weight(sd, p):
+    """Eval-mode torch.nn.utils.spectral_norm: W_orig / (u . (W_mat v)) (util.py:319-322)."""
+    w = sd[p + ".weight_orig"].astype(np.float64)
+    sigma = sd[p + ".weight_u"].astype(np.float64) @ (w.reshape(w.shape[0], -1) @ sd[p + ".weight_v"].astype(np.float64))
+    return w / sigma
+
+
+def pack_conv(w, cout_pad):
+    """w: [Cout, Cin, (KD,) KH, KW] -> fp16 [nchunks*KD*KH*KW, cout_pad, 32]."""
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim == 4:
+        w = w[:, :, None]
+    co, ci, kd, kh, kw = w.shape
+    nch = (ci + 31) // 32
+    full = np.zeros((cout_pad, nch * 32, kd, kh, kw), np.float64)
+    full[:co, :ci] = w
+    full = full.reshape(cout_pad, nch, 32, kd, kh, kw).transpose(1, 3, 4, 5, 0, 2)
+    return np.ascontiguousarray(full.reshape(nch * kd * kh * kw, cout_pad, 32).astype(np.float16))
+
+
+def unpack_conv(packed, cout, cin, kd, kh, kw):
+    """Inverse of pack_conv (tests)."""
+    nch = (cin + 31) // 32
+    cout_pad = packed.shape[1]
+    full = packed.astype(np.float32).reshape(nch, kd, kh, kw, cout_pad, 32).transpose(4, 0, 5, 1, 2, 3)
+    return full.reshape(cout_pad, nch * 32, kd, kh, kw)[:cout, :cin]
+
+
+def interleave16(a, b):
+    """Rows of a and b interleaved in blocks of 16: [a0..15, b0..15, a16..31, b16..31, ...]."""
+    c = a.shape[0]
+    assert c % 16 == 0 and a.shape == b.shape
+    out = np.empty((2 * c,) + a.shape[1:], a.dtype)
+    v = out.reshape((c // 16, 2, 16) + a.shape[1:])
+    v[:, 0] = a.reshape((c // 16, 16) + a.shape[1:])
+    v[:, 1] = b.reshape((c // 16, 16) + a.shape[1:])
+    return out
+
+
+def _f32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def _pad(v, n):
+    out = np.zeros(n, np.float64)
+    out[: len(v)] = v
+    return out
+
+
+def _resblocks3d(out, prefix, sd):
+    """6x ResBlock3d (util.py:80-102): conv1 carries norm2; norm1 of the next block rides on conv2's epilogue."""
+    for i in range(6):
+        p = f"resblocks_3d.3dr{i}"
+        s2, t2 = bn_affine(sd, p + ".norm2")
+        w1, b1 = fold_conv_bn(sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], s2, t2)
+        out[f"{prefix}.rb{i}.c1.w"] = pack_conv(w1, 32)
+        out[f"{prefix}.rb{i}.c1.b"] = _f32(b1)
+        out[f"{prefix}.rb{i}.c2.w"] = pack_conv(sd[p + ".conv2.weight"], 32)
+        out[f"{prefix}.rb{i}.c2.b"] = _f32(sd[p + ".conv2.bias"])
+        if i < 5:
+            s, t = bn_affine(sd, f"resblocks_3d.3dr{i + 1}.norm1")
+            out[f"{prefix}.rb{i}.post.s"] = _f32(s)
+            out[f"{prefix}.rb{i}.post.t"] = _f32(t)
+    s, t = bn_affine(sd, "resblocks_3d.3dr0.norm1")   # pre-activation of block 0, per memory channel jm (c = jm % 32)
+    out[f"{prefix}.pre0.s"] = _f32(np.tile(s, 16))
+    out[f"{prefix}.pre0.t"] = _f32(np.tile(t, 16))
+
+
+def _pack_F(out, sd):
+    s, t = bn_affine(sd, "first.norm")
+    w, b = fold_conv_bn(sd["first.conv.weight"], sd["first.conv.bias"], s, t)
+    out["F.first.w"] = _f32(w.reshape(64, 27))
+    out["F.first.b"] = _f32(b)
+    for i, (co) in enumerate((128, 256)):
+        s, t = bn_affine(sd, f"down_blocks.{i}.norm")
+        w, b = fold_conv_bn(sd[f"down_blocks.{i}.conv.weight"], sd[f"down_blocks.{i}.conv.bias"], s, t)
+        out[f"F.down{i}.w"] = pack_conv(w, co)
+        out[f"F.down{i}.b"] = _f32(b)
+    out["F.second.w"] = pack_conv(sd["second.weight"][MEM2REF], 512)
+    out["F.second.b"] = _f32(sd["second.bias"][MEM2REF])
+    _resblocks3d(out, "F", sd)
+
+
+def _pack_W(out, sd):
+    p = "dense_motion_network"
+    s, t = bn_affine(sd, p + ".norm")
+    w, b = fold_conv_bn(sd[p + ".compress.weight"], sd[p + ".compress.bias"], s, t)
+    out["W.compress.w"] = _f32(w.reshape(4, 32))
+    out["W.compress.b"] = _f32(b)
+    for kind, blocks in (("enc", "encoder.down_blocks"), ("dec", "decoder.up_blocks")):
+        for i in range(5):
+            q = f"{p}.hourglass.{blocks}.{i}"
+            s, t = bn_affine(sd, q + ".norm")
+            w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
+            out[f"W.{kind}{i}.w"] = pack_conv(w, w.shape[0])
+            out[f"W.{kind}{i}.b"] = _f32(b)
+    q = p + ".hourglass.decoder"
+    s, t = bn_affine(sd, q + ".norm")
+    w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
+    out["W.tail.w"] = pack_conv(w, 192)
+    out["W.tail.b"] = _f32(_pad(b, 144))
+    out["W.mask.w"] = pack_conv(sd[p + ".mask.weight"], 32)
+    out["W.mask.b"] = _f32(_pad(sd[p + ".mask.bias"], 32))
+    wo = sd[p + ".occlusion.weight"].reshape(142, 16, 7, 7)          # channel j = c*16 + d (dense_motion.py:100)
+    occ = np.zeros((16, 7, 7, 144), np.float32)
+    occ[..., :142] = wo.transpose(1, 2, 3, 0)
+    out["W.occ.w"] = np.ascontiguousarray(occ.astype(np.float16))
+    out["W.occ.b"] = _f32(sd[p + ".occlusion.bias"].reshape(1))
+    s, t = bn_affine(sd, "third.norm")
+    w, b = fold_conv_bn(sd["third.conv.weight"][:, MEM2REF], sd["third.conv.bias"], s, t)
+    out["W.third.w"] = pack_conv(w, 256)
+    out["W.third.b"] = _f32(b)
+    out["W.fourth.w"] = pack_conv(sd["fourth.weight"], 256)
+    out["W.fourth.b"] = _f32(sd["fourth.bias"])
+
+
+def _pack_T(out, sd):
+    for i in range(7):
+        for j in (1, 2):
+            p = f"BottleNeck_2d.{i}.conv{j}"
+            n = f"T.b{i}.c{j}"
+            w = sd[p + ".weight"][MEM2REF][:, MEM2REF]                      # [o_m][i_m][3][3]
+            out[n + ".w"] = pack_conv(interleave16(w, np.zeros_like(w)), 1024)   # rows: W | (w_mod filled by cs_set_identity)
+            out[n + ".raw"] = _f32(w.transpose(0, 2, 3, 1).reshape(512, 9, 512))
+            out[n + ".fc"] = _f32(np.concatenate([
+                sd[p + ".style_fc.0.weight"].reshape(-1), sd[p + ".style_fc.0.bias"],
+                sd[p + ".style_fc.2.weight"][MEM2REF].reshape(-1), sd[p + ".style_fc.2.bias"][MEM2REF]]))
+            out[n + ".bias"] = _f32(sd[p + ".bias_param"][MEM2REF])
+            out[n + ".mask.w"] = pack_conv(sd[p + ".mask_conv.0.weight"][:, MEM2REF], 16)
+            out[n + ".mask.b"] = _f32(_pad(sd[p + ".mask_conv.0.bias"], 4))
+    _resblocks3d(out, "T", sd)
+
+
+def _pack_R(out, sd):
+    for name, blk in (("s1", "resblocks1"), ("s3", "resblocks3")):
+        for i in range(3):
+            p, n = f"{blk}.{i}", f"R.{name}.{i}"
+            for c in ("1", "2"):
+                out[f"{n}.c{c}.w"] = pack_conv(sd[f"{p}.conv{c}.weight"], 32)
+                out[f"{n}.c{c}.b"] = _f32(sd[f"{p}.conv{c}.bias"])
+                out[f"{n}.gn{c}.w"] = _f32(sd[f"{p}.gn{c}.weight"])
+                out[f"{n}.gn{c}.b"] = _f32(sd[f"{p}.gn{c}.bias"])
+    for i in range(3):
+        p, n = f"resblocks2.{i}", f"R.rb2.{i}"
+        s2, t2 = bn_affine(sd, p + ".norm2")
+        w1, b1 = fold_conv_bn(sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], s2, t2)
+        out[n + ".c1.w"] = pack_conv(w1[MEM2REF][:, MEM2REF], 512)
+        out[n + ".c1.b"] = _f32(b1[MEM2REF])
+        out[n + ".c2.w"] = pack_conv(sd[p + ".conv2.weight"][MEM2REF][:, MEM2REF], 512)
+        out[n + ".c2.b"] = _f32(sd[p + ".conv2.bias"][MEM2REF])
+        s1, t1 = bn_affine(sd, p + ".norm1")
+        out[n + ".pre.s"] = _f32(s1[MEM2REF])
+        out[n + ".pre.t"] = _f32(t1[MEM2REF])
+
+
+def _pack_gb(out, n, sd, p):
+    g, b = sd[p + ".mlp_gamma.weight"], sd[p + ".mlp_beta.weight"]
+    c = g.shape[0]
+    out[n + ".w"] = pack_conv(interleave16(g, b), ((2 * c + 127) // 128) * 128)
+    out[n + ".bg"] = _f32(sd[p + ".mlp_gamma.bias"])
+    out[n + ".bb"] = _f32(sd[p + ".mlp_beta.bias"])
+
+
+def _pack_G(out, sd):
+    out["G.fc.w"] = pack_conv(sd["fc.weight"], 512)
+    out["G.fc.b"] = _f32(sd["fc.bias"])
+    groups = {
+        "G.shared64": [f"G_middle_{b}.norm_{k}" for b in range(6) for k in (0, 1)],
+        "G.shared128": ["up_0.norm_0", "up_0.norm_1", "up_0.norm_s"],
+        "G.shared256": ["up_1.norm_0", "up_1.norm_1", "up_1.norm_s"],
+    }
+    for n, lst in groups.items():
+        w = np.concatenate([sd[q + ".mlp_shared.0.weight"] for q in lst], 0)
+        out[n + ".w"] = pack_conv(w, w.shape[0])
+        out[n + ".b"] = _f32(np.concatenate([sd[q + ".mlp_shared.0.bias"] for q in lst]))
+    blocks = [(f"G.m{b}", f"G_middle_{b}") for b in range(6)] + [("G.up0", "up_0"), ("G.up1", "up_1")]
+    for n, p in blocks:
+        for k in ("0", "1"):
+            _pack_gb(out, f"{n}.n{k}", sd, f"{p}.norm_{k}")
+            w = spectral_weight(sd, f"{p}.conv_{k}")
+            out[f"{n}.c{k}.w"] = pack_conv(w, w.shape[0])
+            out[f"{n}.c{k}.b"] = _f32(sd[f"{p}.conv_{k}.bias"])
+        if p + ".conv_s.weight_orig" in sd:
+            _pack_gb(out, f"{n}.ns", sd, f"{p}.norm_s")
+            w = spectral_weight(sd, f"{p}.conv_s")
+            out[f"{n}.cs.w"] = pack_conv(w, w.shape[0])
+            out[f"{n}.cs.b"] = _f32(np.zeros(w.shape[0]))
+    out["G.img.w"] = pack_conv(sd["conv_img.0.weight"], 16)
+    out["G.img.b"] = _f32(_pad(sd["conv_img.0.bias"], 16))
+
+
+def _np_sd(sd):
+    return {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+
+
+def build_blobs(state_dicts: dict) -> dict:
+    """``state_dicts``: {'appearance_feature_extractor', 'warping_module', 'spade_generator', 'transfer',
+    'refine'} -> {blob name: contiguous ndarray}; values may be torch tensors or numpy arrays."""
+    out: dict = {}
+    _pack_F(out, _np_sd(state_dicts["appearance_feature_extractor"]))
+    _pack_W(out, _np_sd(state_dicts["warping_module"]))
+    _pack_T(out, _np_sd(state_dicts["transfer"]))
+    _pack_R(out, _np_sd(state_dicts["refine"]))
+    _pack_G(out, _np_sd(state_dicts["spade_generator"]))
+    return out

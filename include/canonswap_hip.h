@@ -1,0 +1,99 @@
+/* canonswap_hip.h -- C ABI of the MI355X (gfx950) CanonSwap generator engine.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class `can_swapper`
+ * (src/can_swap_e2e.py:39) whose stage methods/attributes the pipeline calls once per frame
+ * (src/can_swap_pipeline_e2e.py:242-263).  Every entry point below replaces one of those calls and keeps
+ * its tensor signature: all tensors are caller-owned, contiguous fp32 device buffers in the reference's
+ * NCHW / NCDHW layouts, passed as raw pointers (`tensor.data_ptr()`), and all work is enqueued on the
+ * caller's HIP stream (`torch.cuda.current_stream().cuda_stream`).  The engine owns its packed weights,
+ * per-identity modulated weights and workspace; nothing it allocates is returned.
+ *
+ * Error convention: every function returns 0 on success, non-zero on failure with a message available
+ * from cs_last_error() (thread local).  No C++ exception crosses this boundary.
+ * Threading: an engine is bound to one device and is not thread-safe.
+ */
+#ifndef CANONSWAP_HIP_H
+#define CANONSWAP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_engine cs_engine;
+
+/* ---- life cycle (replaces can_swapper.__init__ / load_cpk, src/can_swap_e2e.py:44-100) */
+int cs_create(int device_id, int max_batch, cs_engine** out);
+void cs_destroy(cs_engine* e);
+const char* cs_last_error(void);
+int cs_abi_version(void);
+/* Upload one packed weight blob (host pointer).  Names/layouts are produced by canonswap_amd/pack.py from
+ * the reference's state-dict keys (BatchNorm / spectral norm folded, channels-last, fp16 MFMA order). */
+int cs_upload(cs_engine* e, const char* name, const void* host_ptr, size_t nbytes);
+int cs_finalize_weights(cs_engine* e);
+/* Per-identity precompute of the 14 modulated+demodulated conv weights of T
+ * (AdaptiveSharedWeightConv2d.forward, src/modules/adaptive_modulate.py:148-155).  id: device, 512 fp32. */
+int cs_set_identity(cs_engine* e, int slot, const float* id, void* stream);
+
+/* ---- stage calls; B frames per call, B <= max_batch --------------------------------------------------- */
+/* can_swapper.extract_feature_3d (can_swap_e2e.py:165-172): img Bx3x256x256 -> f Bx32x16x64x64 */
+int cs_extract_feature_3d(cs_engine* e, int B, const float* img, float* f_out, void* stream);
+/* WarpingNetwork.warp(feature_3d, kp_source, kp_driving) (warping_network.py:49-62):
+ * f Bx32x16x64x64, kp Bx21x3 -> f_out Bx32x16x64x64, occ_out Bx1x64x64 */
+int cs_warp(cs_engine* e, int B, const float* f, const float* kp_source, const float* kp_driving, float* f_out,
+            float* occ_out, void* stream);
+/* WarpingNetwork.warp_out(out, occlusion_map) (warping_network.py:64-71): -> seg Bx256x64x64; occ may be NULL */
+int cs_warp_out(cs_engine* e, int B, const float* f, const float* occ, float* seg_out, void* stream);
+/* transfer_model2.forward(x, dlatents) == can_swapper.swap (adaptive_modulate.py:522-554), identity from slot */
+int cs_swap(cs_engine* e, int slot, int B, const float* f, float* f_out, void* stream);
+/* G3d.forward (adaptive_modulate.py:721-733) */
+int cs_refine(cs_engine* e, int B, const float* f, float* f_out, void* stream);
+/* WarpingNetwork.forward(feature_3d, kp_driving=, kp_source=) (warping_network.py:83-111):
+ * any of occ_out (Bx1x64x64), deformation_out (Bx16x64x64x3), seg_out (Bx256x64x64) may be NULL */
+int cs_warp_forward(cs_engine* e, int B, const float* f, const float* kp_driving, const float* kp_source,
+                    float* occ_out, float* deformation_out, float* seg_out, void* stream);
+/* SPADEDecoder.forward (spade_generator.py:41-59): seg Bx256x64x64 -> img Bx3x512x512 in (0,1) */
+int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img_out, void* stream);
+/* can_swapper.parse_output on device (can_swap_e2e.py:314-322): Bx3xHxW fp32 -> BxHxWx3 u8 (truncation) */
+int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W, void* stream);
+/* The whole per-frame loop body (can_swap_pipeline_e2e.py:242-263) for B frames without leaving the device:
+ * img Bx3x256x256, x_t / x_can Bx21x3.  out_f32 (Bx3x512x512), out_u8 (Bx512x512x3), rec_can, swap_can
+ * (debug decodes of lines 248 / 257, Bx3x512x512) may each be NULL. */
+int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
+                   float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream);
+
+/* ---- measurement: per-kernel-family HIP-event timing on the launch stream */
+int cs_profile_begin(cs_engine* e);
+/* ms[0] = conv_igemm kernels, ms[1] = all other kernels; counts likewise; flops = algorithmic conv FLOPs
+ * (2*MAC over the reference's logical channel counts) enqueued since cs_profile_begin */
+int cs_profile_end(cs_engine* e, double ms[2], long counts[2], double* flops);
+
+/* ---- operator level (unit parity tests) ---------------------------------------------------------------- */
+typedef struct cs_conv_desc {
+    const void* in;           /* fp16 channels-last */
+    long in_sN, in_sD, in_sH, in_sW;
+    int N, D, H, W, Cin, up_shift;
+    int KD, KH, KW;
+    const void* wgt;          /* packed fp16 (pack.py pack_conv) */
+    int Cout_pad, Cout;
+    const float* bias; const float* bias2;
+    int act0; float slope0;
+    const void* res; int res_f32; int res_shift; long res_sN, res_sD, res_sH, res_sW;
+    const float* pixscale; int ps_stride;
+    void* out0; int out0_f32; long out0_sN, out0_sD, out0_sH, out0_sW;
+    const float* s2; const float* t2; int act1; float slope1;
+    void* out1; long out1_sN, out1_sD, out1_sH, out1_sW;
+    const float* stats; float stat_cnt_inv; float eps;
+    int mode;                 /* 0 std, 1 T blend, 2 SPADE, 3 pixel-shuffle + sigmoid */
+    int cfg;                  /* -1 auto, else tile configuration */
+    int tile_w, tile_h;       /* 0 = auto */
+} cs_conv_desc;
+int cs_op_conv(const cs_conv_desc* d, void* stream);
+int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,
+                        void* stream);
+int cs_op_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

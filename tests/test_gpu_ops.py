@@ -1,0 +1,211 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 CPU ops."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _randn(r, *shape, scale=1.0):
+    return torch.from_numpy((scale * r.standard_normal(shape)).astype(np.float32))
+
+
+def _to_cl(x):
+    """NC(D)HW fp32 -> [N, D, H, W, C] fp16 channels-last (contiguous)."""
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    return x.permute(0, 2, 3, 4, 1).contiguous().half()
+
+
+def _from_cl(y):
+    """[N, D, H, W, C] -> NCDHW fp32 cpu."""
+    return y.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _ref_conv(x, w, b, pad):
+    return F.conv3d(x.half().float(), w.half().float(), b, padding=pad)
+
+
+CASES = [
+    # name, N, Cin, Cout, D, H, W, k, cfg
+    ("2d_3x3_128x128", 2, 64, 128, 1, 32, 32, (1, 3, 3), -1),
+    ("2d_3x3_batch3", 3, 96, 256, 1, 16, 16, (1, 3, 3), -1),
+    ("2d_1x1_n64", 1, 256, 64, 1, 32, 32, (1, 1, 1), -1),
+    ("3d_3x3x3_n32", 1, 32, 32, 16, 16, 16, (3, 3, 3), -1),
+    ("3d_small_spatial", 3, 64, 128, 16, 2, 2, (3, 3, 3), -1),
+    ("3d_4x4", 2, 128, 64, 16, 4, 4, (3, 3, 3), -1),
+    ("2d_n16", 1, 64, 16, 1, 32, 32, (1, 3, 3), -1),
+    ("3d_7x7x7", 1, 48, 32, 8, 8, 8, (7, 7, 7), -1),
+]
+
+
+@pytest.mark.parametrize("name,N,Cin,Cout,D,H,W,k,cfg", CASES)
+def test_conv_std(name, N, Cin, Cout, D, H, W, k, cfg):
+    import hip_ops as ops
+    r = _rng(zlib.crc32(name.encode()) % 1000)
+    x = _randn(r, N, Cin, D, H, W)
+    w = _randn(r, Cout, Cin, *k, scale=1.0 / np.sqrt(Cin * np.prod(k)))
+    b = _randn(r, Cout, scale=0.1)
+    ref = F.relu(_ref_conv(x, w, b, tuple(kk // 2 for kk in k)))
+    cout_pad = Cout
+    xd = _to_cl(x).to(DEV)
+    wp = ops.packed_weight(w, cout_pad, DEV)
+    out = torch.zeros(N, D, H, W, Cout, dtype=torch.float32, device=DEV)
+    ops.conv(xd, wp, cout_pad, Cout, k, bias=b.to(DEV), act0="relu", out0=out, cfg=cfg)
+    torch.cuda.synchronize()
+    err = ops.rel_err(_from_cl(out), ref)
+    assert err < 2e-3, (name, err)
+
+
+def test_conv_channel_slice_pad_and_upshift():
+    """Cin = 112 read at channel offset 32 of a 144-wide buffer (dense-motion level 0) with nearest x2 up-sampling
+    folded into addressing (UpBlock3d, util.py:142-147) and output into a wider concat buffer."""
+    import hip_ops as ops
+    r = _rng(11)
+    N, D, Hs, Ws = 2, 4, 8, 8
+    x = _randn(r, N, 110, D, Hs, Ws)
+    w = _randn(r, 64, 110, 3, 3, 3, scale=0.03)
+    b = _randn(r, 64, scale=0.1)
+    xu = x.repeat_interleave(2, 3).repeat_interleave(2, 4)
+    ref = F.relu(_ref_conv(xu, w, b, 1))
+    buf = torch.zeros(N, D, Hs, Ws, 144, dtype=torch.float16, device=DEV)
+    buf[..., 32:142] = _to_cl(x).to(DEV)
+    buf[..., :32] = 7.0                         # neighbouring channels must not leak in
+    wp = ops.packed_weight(w, 64, DEV)
+    obuf = torch.full((N, D, 2 * Hs, 2 * Ws, 96), -5.0, dtype=torch.float16, device=DEV)
+    ops.conv(buf[..., 32:], wp, 64, 64, (3, 3, 3), cin=112, bias=b.to(DEV), act0="relu", out0=obuf[..., :64], up_shift=1,
+             out_dims=(N, D, 2 * Hs, 2 * Ws))
+    torch.cuda.synchronize()
+    assert ops.rel_err(_from_cl(obuf[..., :64]), ref) < 3e-3
+    assert bool((obuf[..., 64:] == -5.0).all())
+
+
+def test_conv_hwdc_residual_dual_output():
+    """3x3x3 conv on the [H][W][D][C] feature-volume layout, fp32 residual stream, second pre-activated fp16 output
+    (ResBlock3d, util.py:94-102)."""
+    import hip_ops as ops
+    r = _rng(12)
+    N, Cc, D, H, W = 2, 32, 16, 8, 8
+    x = _randn(r, N, Cc, D, H, W)
+    res = _randn(r, N, Cc, D, H, W)
+    w = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04)
+    b = _randn(r, Cc, scale=0.1)
+    s2 = torch.from_numpy(r.uniform(0.5, 1.5, Cc).astype(np.float32)); t2 = _randn(r, Cc, scale=0.2)
+    y = _ref_conv(x, w, b, 1) + res
+    y2 = F.relu(y * s2.view(1, -1, 1, 1, 1) + t2.view(1, -1, 1, 1, 1))
+    hwdc = lambda t: t.permute(0, 3, 4, 2, 1).contiguous()           # NCDHW -> N H W D C
+    xd = hwdc(x).half().to(DEV)
+    resd = hwdc(res).to(DEV)
+    view = lambda t: t.permute(0, 3, 1, 2, 4)                        # N H W D C -> logical [N, D, H, W, C] view
+    out0 = torch.zeros(N, H, W, D, Cc, dtype=torch.float32, device=DEV)
+    out1 = torch.zeros(N, H, W, D, Cc, dtype=torch.float16, device=DEV)
+    wp = ops.packed_weight(w, 32, DEV)
+    ops.conv(view(xd), wp, 32, 32, (3, 3, 3), bias=b.to(DEV), res=view(resd), out0=view(out0), s2=s2.to(DEV), t2=t2.to(DEV),
+             act1="relu", out1=view(out1), tile=(4, 4))
+    torch.cuda.synchronize()
+    back = lambda t: t.float().cpu().permute(0, 4, 3, 1, 2)          # N H W D C -> N C D H W
+    assert ops.rel_err(back(out0), y) < 2e-3
+    assert ops.rel_err(back(out1), y2) < 3e-3
+
+
+def test_conv_tblend():
+    """Fused [W ; w_mod] conv + blend epilogue == AdaptiveSharedWeightConv2d (adaptive_modulate.py:139-186)."""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(13)
+    N, Cc, H, W = 2, 128, 16, 16
+    x = _randn(r, N, Cc, H, W)
+    w_std = _randn(r, Cc, Cc, 3, 3, scale=0.03); w_mod = _randn(r, Cc, Cc, 3, 3, scale=0.03)
+    bias = _randn(r, Cc, scale=0.1)
+    mask = torch.from_numpy(r.uniform(0, 1, (N, 1, H, W)).astype(np.float32))
+    res = _randn(r, N, Cc, H, W)
+    xq = x.half().float()
+    ref = mask * (F.conv2d(xq, w_mod.half().float(), None, padding=1) + bias.view(1, -1, 1, 1)) + \
+        (1 - mask) * F.conv2d(xq, w_std.half().float(), None, padding=1) + res
+    wp = torch.from_numpy(pack.pack_conv(pack.interleave16(w_std.numpy(), w_mod.numpy()), 2 * Cc)).to(DEV)
+    m4 = torch.zeros(N, H, W, 4, dtype=torch.float32, device=DEV); m4[..., 0] = mask[:, 0].to(DEV)
+    out = torch.zeros(N, 1, H, W, Cc, dtype=torch.float32, device=DEV)
+    resd = res.permute(0, 2, 3, 1).contiguous().unsqueeze(1).to(DEV)
+    ops.conv(_to_cl(x).to(DEV), wp, 2 * Cc, Cc, (1, 3, 3), bias=bias.to(DEV), pixscale=m4, ps_stride=4, res=resd, out0=out, mode=1,
+             cfg=0)
+    torch.cuda.synchronize()
+    assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 2e-3
+
+
+@pytest.mark.parametrize("xshift", [0, 1])
+def test_conv_spade(xshift):
+    """gamma/beta convs + instance-norm modulation epilogue == SPADE.forward (util.py:295-302) + leaky_relu(0.2)."""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(14 + xshift)
+    N, Cc, S = 2, 64, 32
+    Sx = S >> xshift
+    actv = _randn(r, N, 128, S, S)
+    x = _randn(r, N, Cc, Sx, Sx) * 2 + 0.5
+    wg = _randn(r, Cc, 128, 3, 3, scale=0.02); wb = _randn(r, Cc, 128, 3, 3, scale=0.02)
+    bg = _randn(r, Cc, scale=0.1); bb = _randn(r, Cc, scale=0.1)
+    xq = x.half().float()
+    xn = (xq - xq.mean((2, 3), keepdim=True)) / torch.sqrt(xq.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
+    if xshift:
+        xn = xn.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    aq = actv.half().float()
+    ref = F.leaky_relu(xn * (1 + F.conv2d(aq, wg.half().float(), bg, padding=1)) + F.conv2d(aq, wb.half().float(), bb, padding=1), 0.2)
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    stats = ops.chan_stats(xd.reshape(N, Sx * Sx, Cc))
+    wp = torch.from_numpy(pack.pack_conv(pack.interleave16(wg.numpy(), wb.numpy()), 128)).to(DEV)
+    out = torch.zeros(N, 1, S, S, Cc, dtype=torch.float16, device=DEV)
+    ops.conv(_to_cl(actv).to(DEV), wp, 128, Cc, (1, 3, 3), bias=bg.to(DEV), bias2=bb.to(DEV), res=xd.unsqueeze(1), res_shift=xshift,
+             stats=stats, stat_cnt_inv=1.0 / (Sx * Sx), eps=1e-5, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=0)
+    torch.cuda.synchronize()
+    assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
+
+
+def test_conv_pixel_shuffle_sigmoid():
+    """conv 64->12 + PixelShuffle(2) + sigmoid (spade_generator.py:36-39,56-57)."""
+    import hip_ops as ops
+    r = _rng(16)
+    N, S = 2, 32
+    x = _randn(r, N, 64, S, S)
+    w = _randn(r, 12, 64, 3, 3, scale=0.05); b = _randn(r, 12, scale=0.1)
+    ref = torch.sigmoid(F.pixel_shuffle(F.conv2d(x.half().float(), w.half().float(), b, padding=1), 2))
+    wp = ops.packed_weight(w, 16, DEV)
+    b16 = torch.zeros(16); b16[:12] = b
+    out = torch.zeros(N, 3, 2 * S, 2 * S, dtype=torch.float32, device=DEV)
+    ops.conv(_to_cl(x).to(DEV), wp, 16, 16, (1, 3, 3), bias=b16.to(DEV), act0="sigmoid", out0=out, mode=3, cfg=3)
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 2e-3
+
+
+def test_grid_sample_3d():
+    """Trilinear feature warp == F.grid_sample(align_corners=False) (warping_network.py:46-47), incl. out-of-range points."""
+    import hip_ops as ops
+    r = _rng(17)
+    N, Cc, D, H, W = 2, 32, 16, 16, 16
+    x = _randn(r, N, Cc, D, H, W)
+    grid = torch.from_numpy(r.uniform(-1.25, 1.25, (N, D, H, W, 3)).astype(np.float32))
+    ref = F.grid_sample(x, grid, align_corners=False)
+    xd = x.permute(0, 3, 4, 2, 1).contiguous().to(DEV)
+    o32, o16 = ops.grid_sample(xd, grid.to(DEV))
+    torch.cuda.synchronize()
+    assert (o32.cpu().permute(0, 4, 3, 1, 2) - ref).abs().max() < 1e-5
+    assert (o16.float().cpu().permute(0, 4, 3, 1, 2) - ref).abs().max() < 4e-3
+
+
+@pytest.mark.parametrize("dtype,Cc,P", [(torch.float16, 512, 4096), (torch.float32, 32, 65536), (torch.float16, 64, 65536)])
+def test_chan_stats(dtype, Cc, P):
+    import hip_ops as ops
+    r = _rng(18)
+    x = (_randn(r, 2, P, Cc) + 0.3).to(dtype)
+    st = ops.chan_stats(x.to(DEV)).cpu()
+    xf = x.double()
+    assert torch.allclose(st[..., 0].double(), xf.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 1].double(), (xf * xf).sum(1), rtol=1e-4, atol=1e-2)

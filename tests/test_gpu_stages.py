@@ -1,0 +1,133 @@
+"""Stage-level and whole-frame parity of the HIP engine against the oracle and the golden vectors.
+
+Floating-point tolerance (BASELINE.json north_star): PSNR >= 50 dB on the 3x512x512 image in [0,1] against the
+fp32 CPU reference; intermediate feature tensors are checked by relative L2 error.  The engine computes with
+fp16 operands / fp32 accumulation (fp32 residual streams), so bit-exactness is not expected.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PSNR_GATE = 50.0
+
+
+@pytest.fixture(scope="module")
+def swapper(state_dicts):
+    from canonswap_amd.can_swap_e2e import can_swapper
+    return can_swapper(None, state_dicts=state_dicts, max_batch=4)
+
+
+@pytest.fixture(scope="module")
+def case(state_dicts):
+    """Two full-size frames through the oracle (about 15 s of CPU)."""
+    from canonswap_amd import synth
+    from oracle import canonswap_ref as O
+    inp = synth.make_frame_inputs(2, seed=1000, size=256)
+    idv = torch.from_numpy(synth.make_identity(7))
+    args = {k: torch.from_numpy(v) for k, v in inp.items()}
+    ref = O.swap_frame(state_dicts, args["img"], args["x_t"], args["x_can"], idv, debug=True)
+    return args, idv, ref
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def test_extract_feature_3d(swapper, case):
+    args, _, ref = case
+    f = swapper.extract_feature_3d(args["img"].cuda())
+    assert f.shape == (2, 32, 16, 64, 64) and f.dtype == torch.float32
+    assert _rel(f, ref["f_s"]) < 3e-3
+
+
+def test_warp(swapper, case):
+    args, _, ref = case
+    f_can, occ = swapper.warping_module.warp(ref["f_s"].cuda(), args["x_t"].cuda(), args["x_can"].cuda())
+    assert _rel(occ, ref["occ"]) < 5e-3
+    assert _rel(f_can, ref["f_can"]) < 5e-3
+
+
+def test_swap_module(swapper, case):
+    _, idv, ref = case
+    out = swapper.swap_module(ref["f_can"].cuda(), idv.cuda())
+    assert _rel(out, ref["f_swap"]) < 3e-3
+
+
+def test_refine_module(swapper, case):
+    _, _, ref = case
+    out = swapper.refine_module(ref["f_swap"].cuda())
+    assert _rel(out, ref["f_ref"]) < 5e-3
+
+
+def test_warp_decode(swapper, case):
+    from oracle import canonswap_ref as O
+    args, _, ref = case
+    ret = swapper.warp_decode(ref["f_ref"].cuda(), args["x_can"].cuda(), args["x_t"].cuda())
+    assert _rel(ret["deformation"], ref["deformation"]) < 2e-3
+    assert _rel(ret["occlusion_map"], ref["occ2"]) < 1e-2
+    assert O.psnr(ret["out"].cpu(), ref["out"]) >= PSNR_GATE
+
+
+def test_conv_decode(swapper, case):
+    from oracle import canonswap_ref as O
+    _, _, ref = case
+    img = swapper.conv_decode(ref["f_can"].cuda(), ref["occ"].cuda())
+    assert O.psnr(img.cpu(), ref["rec_can"]) >= PSNR_GATE
+    seg = swapper.warping_module.warp_out(ref["f_ref"].cuda(), ref["occ2"].cuda())
+    assert _rel(seg, ref["seg"]) < 5e-3
+
+
+def test_swap_frames_psnr_and_debug(swapper, case):
+    """Whole loop body (can_swap_pipeline_e2e.py:242-263) for B=2 including the two debug decodes."""
+    from oracle import canonswap_ref as O
+    args, idv, ref = case
+    r = swapper.swap_frames(args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), idv.cuda(), debug=True, want_u8=True)
+    for k in ("out", "rec_can", "swap_can"):
+        p = O.psnr(r[k].cpu(), ref[k])
+        assert p >= PSNR_GATE, (k, p)
+    u8 = r["out_u8"].cpu().numpy()
+    assert u8.shape == (2, 512, 512, 3) and u8.dtype == np.uint8
+    assert np.array_equal(u8, O.parse_output(r["out"]))                     # device pack == reference parse_output
+    assert np.abs(u8.astype(np.int32) - O.parse_output(ref["out"]).astype(np.int32)).max() <= 3
+    assert np.array_equal(swapper.parse_output(r["out"]), u8)
+
+
+def test_golden_full_size_frame(swapper, golden):
+    """The committed reference output (tests/golden, produced by the reference's own modules)."""
+    from canonswap_amd import synth
+    from oracle import canonswap_ref as O
+    g = golden("frame_256_b1.npz")
+    inp = synth.make_frame_inputs(1, seed=int(g["frame_seed"]), size=256)
+    idv = torch.from_numpy(synth.make_identity(int(g["id_seed"])))
+    r = swapper.swap_frames(*(torch.from_numpy(inp[k]).cuda() for k in ("img", "x_t", "x_can")), idv.cuda())
+    assert O.psnr(r["out"].cpu(), torch.from_numpy(g["out_f16"].astype(np.float32))) >= PSNR_GATE
+
+
+def test_batch_independence_and_determinism(swapper, case):
+    """Frames are independent units (no temporal state): B=1 twice == B=2; the same call twice is stable."""
+    args, idv, _ = case
+    a = swapper.swap_frames(args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), idv.cuda())["out"].clone()
+    b0 = swapper.swap_frames(args["img"][:1].cuda(), args["x_t"][:1].cuda(), args["x_can"][:1].cuda(), idv.cuda())["out"].clone()
+    b1 = swapper.swap_frames(args["img"][1:].cuda(), args["x_t"][1:].cuda(), args["x_can"][1:].cuda(), idv.cuda())["out"].clone()
+    assert (a[0] - b0[0]).abs().max() < 2e-3 and (a[1] - b1[0]).abs().max() < 2e-3
+    a2 = swapper.swap_frames(args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), idv.cuda())["out"]
+    assert (a - a2).abs().max() < 2e-3
+
+
+def test_identity_changes_output(swapper, case):
+    from canonswap_amd import synth
+    args, idv, _ = case
+    other = torch.from_numpy(synth.make_identity(8))
+    a = swapper.swap_frames(args["img"][:1].cuda(), args["x_t"][:1].cuda(), args["x_can"][:1].cuda(), idv.cuda())["out"].clone()
+    b = swapper.swap_frames(args["img"][:1].cuda(), args["x_t"][:1].cuda(), args["x_can"][:1].cuda(), other.cuda())["out"]
+    assert (a - b).abs().mean() > 1e-4
+
+
+def test_errors_are_loud(swapper):
+    with pytest.raises(ValueError):
+        swapper.extract_feature_3d(torch.zeros(1, 3, 128, 128).cuda())
+    with pytest.raises(ValueError):
+        swapper.extract_feature_3d(torch.zeros(9, 3, 256, 256).cuda())        # > max_batch
