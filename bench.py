@@ -1,0 +1,150 @@
+"""bench.py -- frames/sec of the CanonSwap generator hot path at 512x512 output on N MI355X.
+
+One "step" = one pass of the per-frame loop body (F -> W.warp -> T -> R -> W.forward -> G,
+src/can_swap_pipeline_e2e.py:242-263, debug decodes off) over a batch of B synthetic frames per GPU, inputs
+already resident in HBM.  Frames shard across ranks (weak scaling: B frames per GPU per step); the source
+identity is broadcast once over RCCL before the timed region and the uint8 output frames are gathered to
+rank 0 inside it.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_GFLOP_PER_FRAME = 2374.3      # 2*MAC of every conv on the primary path, as the reference runs it
+PEAK_TFLOPS_F16 = 2500.0           # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "8")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from canonswap_amd import parallel, synth
+    from canonswap_amd.can_swap_e2e import can_swapper
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs a {a.gpus}-rank launch (WORLD_SIZE={world}); use torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+
+    B, K, Wm = a.batch, a.steps, a.warmup
+    sds = synth.to_torch(synth.make_state_dicts(0))                     # random-init weights of the real architecture
+    sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), state_dicts=sds, max_batch=B)
+    eng = sw.engine
+
+    # one-time broadcast of the source identity (2 KB); every rank derives T's modulated weights locally
+    sid = torch.from_numpy(synth.make_identity(7)).to(dev) if rank == 0 else torch.zeros(1, 512, device=dev)
+    parallel.broadcast_identity(sid, src=0)
+    eng.set_identity(sid)
+
+    # synthetic inputs resident in HBM: a pool of 4 distinct batches per rank, cycled over the steps
+    pool = []
+    for j in range(4):
+        inp = synth.make_frame_inputs(B, seed=1000 + 10007 * rank + 131 * j, size=256)
+        pool.append([torch.from_numpy(inp[k]).to(dev) for k in ("img", "x_t", "x_can")])
+    out_u8 = torch.empty(K * B, 512, 512, 3, dtype=torch.uint8, device=dev)
+
+    def step(i, slot):
+        eng.swap_frames(*pool[i % 4], want_f32=False, want_u8=True, out_u8=out_u8[slot * B:(slot + 1) * B])
+
+    for i in range(Wm):
+        step(i, 0)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    sync()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i, i)
+    gathered = parallel.gather_frames(out_u8, K * B * world, dst=0) if world > 1 else out_u8   # final gather over xGMI
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        assert gathered.shape[0] == K * B * world
+
+    # ---- roofline of the dominant kernel family (conv_igemm): HIP events around every launch, same workload
+    prof = None
+    if rank == 0:
+        eng.profile_begin()
+        for i in range(K):
+            step(i, i)
+        prof = eng.profile_end()
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import canonswap_ref as O          # cpu_baseline leg: the oracle timed on this node's host cores
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        inp = synth.make_frame_inputs(1, seed=1000, size=256)
+        cargs = [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")]
+        cid = torch.from_numpy(synth.make_identity(7))
+        O.swap_frame(sds, *cargs, cid)                 # warm-up frame
+        n_cpu, t1 = 2, time.perf_counter()
+        for _ in range(n_cpu):
+            O.swap_frame(sds, *cargs, cid)
+        cdt = time.perf_counter() - t1
+        cpu = {"value": round(n_cpu / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n_cpu} frames (1 warm-up), batch 1, fp32 PyTorch-CPU restatement of the same path (oracle/)"}
+
+    if rank == 0:
+        frames = K * B * world
+        fps = frames / dt
+        conv_s = prof["conv_ms"] / 1e3
+        achieved = prof["conv_flops"] / conv_s / 1e12
+        line = {
+            "metric": "frames/sec at 512x512 (generator hot path F->W->T->R->W->G)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 512x512 video, frames batched on each GPU (256x256 crops in, "
+                                   "random-init weights of the real architecture)",
+                       "frames_per_step_per_gpu": B, "frames_total": frames, "parallelism": f"frame-shard x{world}",
+                       "accumulate": "fp32", "debug_decodes": False},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": None,
+                         "kernel": "conv_igemm (all instantiations)", "launches_per_step": prof["conv_launches"] // K,
+                         "avg_launch_us": round(prof["conv_ms"] * 1e3 / prof["conv_launches"], 2),
+                         "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * B) / 1e9, 1),
+                         "other_kernels_ms_per_step": round(prof["other_ms"] / K, 3),
+                         "conv_ms_per_step": round(prof["conv_ms"] / K, 3),
+                         "end_to_end_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / world / (PEAK_TFLOPS_F16 * 1e12), 4)},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,13 +71,16 @@ def test_warp_decode(swapper, case):
     assert O.psnr(ret["out"].cpu(), ref["out"]) >= PSNR_GATE
 
 
-def test_conv_decode(swapper, case):
+def test_conv_decode(swapper, case, state_dicts):
     from oracle import canonswap_ref as O
     _, _, ref = case
     img = swapper.conv_decode(ref["f_can"].cuda(), ref["occ"].cuda())
     assert O.psnr(img.cpu(), ref["rec_can"]) >= PSNR_GATE
     seg = swapper.warping_module.warp_out(ref["f_ref"].cuda(), ref["occ2"].cuda())
-    assert _rel(seg, ref["seg"]) < 5e-3
+    with torch.no_grad():
+        assert _rel(seg, O.warp_out(state_dicts["warping_module"], ref["f_ref"], ref["occ2"])) < 5e-3
+        seg_noocc = swapper.warping_module.warp_out(ref["f_ref"].cuda())
+        assert _rel(seg_noocc, O.warp_out(state_dicts["warping_module"], ref["f_ref"], None)) < 5e-3
 
 
 def test_swap_frames_psnr_and_debug(swapper, case):

@@ -1,0 +1,89 @@
+"""CPU-side checks: weight packer, C-ABI surface, host helpers (no GPU compute)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from canonswap_amd import pack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pack_conv_roundtrip_and_kstep_order():
+    r = np.random.Generator(np.random.PCG64(3))
+    w = r.standard_normal((22, 142, 7, 7, 7)).astype(np.float32)
+    p = pack.pack_conv(w, 32)
+    assert p.shape == (5 * 343, 32, 32) and p.dtype == np.float16
+    assert np.array_equal(pack.unpack_conv(p, 22, 142, 7, 7, 7), w.astype(np.float16).astype(np.float32))
+    # kstep = ((chunk*KD+kd)*KH+kh)*KW+kw, in-channel = chunk*32 + kk
+    chunk, kd, kh, kw, row, kk = 3, 2, 5, 1, 7, 9
+    assert p[((chunk * 7 + kd) * 7 + kh) * 7 + kw, row, kk] == np.float16(w[row, chunk * 32 + kk, kd, kh, kw])
+    assert np.all(p[:, 22:, :] == 0) and np.all(p[4 * 343:, :, 14:] == 0)      # padded rows / channels are zero
+
+
+def test_interleave16():
+    a = np.arange(32)[:, None] * np.ones((1, 3)); b = -a
+    z = pack.interleave16(a, b)
+    assert z.shape == (64, 3)
+    assert np.array_equal(z[:16], a[:16]) and np.array_equal(z[16:32], b[:16]) and np.array_equal(z[32:48], a[16:])
+
+
+def test_bn_and_spectral_folding_match_oracle(state_dicts_np, state_dicts):
+    from oracle import canonswap_ref as O
+    sd, sdt = state_dicts_np["appearance_feature_extractor"], state_dicts["appearance_feature_extractor"]
+    s, t = pack.bn_affine(sd, "down_blocks.0.norm")
+    w, b = pack.fold_conv_bn(sd["down_blocks.0.conv.weight"], sd["down_blocks.0.conv.bias"], s, t)
+    x = torch.randn(1, 64, 8, 8)
+    ref = O.bn_eval(O.conv(x, sdt, "down_blocks.0.conv", 1), sdt, "down_blocks.0.norm")
+    got = F.conv2d(x, torch.from_numpy(w).float(), torch.from_numpy(b).float(), padding=1)
+    assert (ref - got).abs().max() < 1e-4
+    g, gt = state_dicts_np["spade_generator"], state_dicts["spade_generator"]
+    assert np.abs(pack.spectral_weight(g, "up_1.conv_1") - O.spectral_weight(gt, "up_1.conv_1").numpy()).max() < 1e-5
+
+
+def test_view_permutation_is_the_reference_view():
+    """Memory channel jm = d*32 + c of the [H][W][D][C] volume is reference channel c*16 + d of view(bs, c*d, h, w)."""
+    v = torch.arange(32 * 16).view(32, 16)                       # value = reference flat channel index c*16+d
+    mem = v.t().reshape(-1)                                      # [d][c] order
+    assert np.array_equal(mem.numpy(), pack.MEM2REF)
+
+
+def test_build_blobs_names_and_sizes(state_dicts_np):
+    blobs = pack.build_blobs(state_dicts_np)
+    assert blobs["T.b6.c2.w"].shape == (144, 1024, 32) and blobs["T.b0.c1.raw"].shape == (512, 9, 512)
+    assert blobs["W.mask.w"].shape == (1715, 32, 32) and blobs["W.occ.w"].shape == (16, 7, 7, 144)
+    assert blobs["G.shared64.w"].shape == (72, 1536, 32) and blobs["G.up1.n1.w"].shape == (36, 128, 32)
+    assert all(b.flags["C_CONTIGUOUS"] for b in blobs.values())
+    # every blob the engine asks for by literal name exists (names built with snprintf are covered on the GPU)
+    src = open(os.path.join(ROOT, "canonswap_amd", "csrc", "engine.hip")).read()
+    for name in re.findall(r'"((?:F|W|T|R|G)\.[A-Za-z0-9_.]+\.(?:w|b))"', src):
+        assert name in blobs, name
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from canonswap_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "canonswap_hip.h")).read()
+    declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.ABI_SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert lib.cs_abi_version() == 1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    from canonswap_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(0)
+
+
+def test_keypoint_helpers_match_golden(golden):
+    from canonswap_amd.can_swap_e2e import get_rotation_matrix, headpose_pred_to_degree
+    g = golden("unit_vectors.npz")
+    pyr = torch.from_numpy(g["pyr"])
+    assert np.abs(get_rotation_matrix(pyr[:, 0], pyr[:, 1], pyr[:, 2]).numpy() - g["rot"]).max() < 1e-6
+    assert np.abs(headpose_pred_to_degree(torch.from_numpy(g["bins"])).numpy() - g["deg"]).max() < 1e-4

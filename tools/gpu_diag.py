@@ -54,7 +54,8 @@ def main():
             r = sw.warping_module(cu(ref["f_ref"]), kp_source=cu(args["x_can"]), kp_driving=cu(args["x_t"]))
             return (rel(r["deformation"], ref["deformation"]), rel(r["occlusion_map"], ref["occ2"]), rel(r["out"], ref["seg"]))
         chk("W.forward (deform, occ, seg) rel", w2)
-        chk("warp_out seg rel", lambda: rel(sw.warping_module.warp_out(cu(ref["f_ref"]), cu(ref["occ2"])), ref["seg"]))
+        chk("warp_out seg rel", lambda: rel(sw.warping_module.warp_out(cu(ref["f_ref"]), cu(ref["occ2"])),
+                                            O.warp_out(sds["warping_module"], ref["f_ref"], ref["occ2"])))
         chk("G  psnr(seg->img)", lambda: O.psnr(sw.spade_generator(feature=cu(ref["seg"])).cpu(), ref["out"]))
         def full():
             r = sw.swap_frames(cu(args["img"]), cu(args["x_t"]), cu(args["x_can"]), cu(idv), debug=True)
