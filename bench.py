@@ -104,7 +104,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import canonswap_ref as O          # cpu_baseline leg: the oracle timed on this node's host cores
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 32)           # oversubscribing a 256-thread host slows PyTorch-CPU down
         torch.set_num_threads(cores)
         inp = synth.make_frame_inputs(1, seed=1000, size=256)
         cargs = [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")]

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity",
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_swap_frames", "cs_profile_begin", "cs_profile_end", "cs_op_conv", "cs_op_grid_sample3d",
-    "cs_op_chan_stats",
+    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats",
 ]
 
 
@@ -49,7 +49,7 @@ class ConvDesc(C.Structure):
         ("out0_sN", C.c_long), ("out0_sD", C.c_long), ("out0_sH", C.c_long), ("out0_sW", C.c_long),
         ("s2", C.c_void_p), ("t2", C.c_void_p), ("act1", C.c_int), ("slope1", C.c_float),
         ("out1", C.c_void_p), ("out1_sN", C.c_long), ("out1_sD", C.c_long), ("out1_sH", C.c_long), ("out1_sW", C.c_long),
-        ("stats", C.c_void_p), ("stat_cnt_inv", C.c_float), ("eps", C.c_float),
+        ("stats", C.c_void_p),
         ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int),
     ]
 
@@ -88,7 +88,9 @@ def load():
     lib.cs_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
     lib.cs_op_conv.argtypes = [C.POINTER(ConvDesc), vp]
     lib.cs_op_grid_sample3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
-    lib.cs_op_chan_stats.argtypes = [vp, ci, ci, C.c_long, ci, vp, vp]
+    lib.cs_op_chan_stats.argtypes = [vp, ci, ci, C.c_long, ci, cf, vp, vp, vp]
+    lib.cs_op_chan_stats_partial_floats.argtypes = [ci, C.c_long, ci]
+    lib.cs_op_chan_stats_partial_floats.restype = C.c_long
     _lib = lib
     return lib
 

@@ -26,6 +26,7 @@ struct ConvParams {
     const half_t* in;
     long in_sN, in_sD, in_sH, in_sW;
     int N, D, H, W;     // output extents (the input is addressed at (h>>up_shift, w>>up_shift))
+    int inD;            // input depth extent (== D except for the depth-collapsing occlusion conv)
     int Cin;            // valid input channels (multiple of 8)
     int nchunks;        // ceil(Cin / 32)
     int up_shift;       // nearest-neighbour up-sampling of the input folded into addressing
@@ -54,9 +55,7 @@ struct ConvParams {
     int act1;
     float slope1;
     TDesc out1;
-    const float* stats;     // SPADE: [N][C][2] = (sum, sum of squares) of x over its H*W
-    float stat_cnt_inv;
-    float eps;
+    const float* stats;     // SPADE: [N][C][2] = (mean, 1/sqrt(var+eps)) of x over its H*W
 };
 
 #define CS_CHECK_HIP(expr)                                                                  \
@@ -80,11 +79,11 @@ int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, h
                      int H, int W, hipStream_t st);
 int launch_dm_softmax(const float* logits, int lstride, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
                       int N, int D, int H, int W, hipStream_t st);
-int launch_dm_occlusion(const half_t* pred, int C, const half_t* w, float bias, float* occ, int N, int D, int H, int W,
-                        hipStream_t st);
+int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
 int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);
-int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, hipStream_t st);
-int launch_norm_act(const float* y, const float* stats, float cnt_inv, float eps, const float* gamma, const float* beta,
+int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st);
+long chan_stats_partial_floats(int N, long P, int C);
+int launch_norm_act(const float* y, const float* stats, const float* gamma, const float* beta,
                     const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
                     int act2, float slope2, int N, long per_n, hipStream_t st);
 int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,

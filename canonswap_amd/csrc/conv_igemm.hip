@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int id = rd[i] + dd, ih = rh[i] + dh, iw = rw[i] + dw;
-            const bool ok = rn[i] < p.N && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H &&
+            const bool ok = rn[i] < p.N && (unsigned)id < (unsigned)p.inD && (unsigned)ih < (unsigned)p.H &&
                             (unsigned)iw < (unsigned)p.W && cc < p.Cin;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (ok) {
@@ -202,11 +202,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float* st = p.stats + ((long)n * p.Cout + cb + r) * 2;
-                    const float mean = st[0] * p.stat_cnt_inv;
-                    const float var = fmaxf(st[1] * p.stat_cnt_inv - mean * mean, 0.f);
                     const float g = acc[ci][pi][r] + p.bias[cb + r];
                     const float b = acc[ci + CSTEP - 1][pi][r] + p.bias2[cb + r];
-                    v[r] = (x[r] - mean) * rsqrtf(var + p.eps) * (1.f + g) + b;
+                    v[r] = (x[r] - st[0]) * st[1] * (1.f + g) + b;
                 }
             } else {
 #pragma unroll

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -38,6 +39,7 @@ struct ConvL {            // one packed convolution layer
     const float* b = nullptr;
     int Cin = 0, Cout_pad = 0, Cout = 0, KD = 1, KH = 1, KW = 1;
     double macs_per_pos = 0;   // logical (reference) Cin*Cout*taps, for FLOP accounting
+    std::string name;
 };
 
 struct Affine { const float* s = nullptr; const float* t = nullptr; };
@@ -58,8 +60,8 @@ struct cs_engine {
     Affine f_pre0;
     struct RB3 { ConvL c1, c2; Affine post; } f_rb[6], t_rb[6];
     const float *cmp_w = nullptr, *cmp_b = nullptr;
-    ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_third, w_fourth;
-    const half_t* occ_w = nullptr; float occ_b = 0.f;
+    ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_occ, w_third, w_fourth;
+    float occ_b = 0.f;
     TLayer t_l[14];
     Affine t_pre0;
     struct S3 { ConvL c1, c2; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];
@@ -76,14 +78,14 @@ struct cs_engine {
     float *kpbuf;
     half_t *w_t3, *seg16;
     float* tmask; float* style;
-    float* stats_pool; size_t stats_slots = 0, stats_next = 0; size_t stats_slot_floats = 0;
+    float* stats_pool; float* stats_part; float* dm_occpart; size_t stats_slots = 0, stats_next = 0; size_t stats_slot_floats = 0;
     half_t *g_x[2], *g_h64, *g_dx64, *g_a64, *g_a128, *g_a256, *g_h128, *g_xs128, *g_dx128, *g_h1_128, *g_o128;
     half_t *g_h256, *g_xs256, *g_dx256, *g_h1_256, *g_o256;
     float *img_a, *img_b;
 
     // ---- profiling
     bool prof = false;
-    struct Rec { int fam; hipEvent_t a, b; };
+    struct Rec { int fam; hipEvent_t a, b; std::string label; double flops; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;
@@ -94,14 +96,14 @@ struct cs_engine {
         if (evnext == evpool.size()) { hipEvent_t e; hipEventCreate(&e); evpool.push_back(e); }
         return evpool[evnext++];
     }
-    template <class F> int run(int fam, hipStream_t st, F f)
+    template <class F> int run(int fam, hipStream_t st, F f, const char* label = "", double fl = 0)
     {
         if (!prof) return f();
         hipEvent_t a = ev(), b = ev();
         hipEventRecord(a, st);
         int r = f();
         hipEventRecord(b, st);
-        recs.push_back({fam, a, b});
+        recs.push_back({fam, a, b, label, fl});
         return r;
     }
     template <class T> int alloc(T** p, size_t n)
@@ -142,6 +144,7 @@ int get_conv(cs_engine* e, const std::string& n, int Cin, int Cout_pad, int Cout
     if (bias_len > 0) { TRY(need(e, n + ".b", (size_t)bias_len * sizeof(float), &p)); L->b = (const float*)p; }
     L->Cin = Cin; L->Cout_pad = Cout_pad; L->Cout = Cout; L->KD = KD; L->KH = KH; L->KW = KW;
     L->macs_per_pos = macs;
+    L->name = n;
     return 0;
 }
 
@@ -176,6 +179,7 @@ struct ConvCall {
     ConvParams p;
     int cfg = -1, mode = MODE_STD;
     double macs_per_pos = 0;
+    const char* name = "";
 };
 
 ConvCall mk(const ConvL& L, const void* in, TDesc ind, int N, int D, int H, int W, int up_shift = 0)
@@ -185,13 +189,14 @@ ConvCall mk(const ConvL& L, const void* in, TDesc ind, int N, int D, int H, int 
     ConvParams& p = c.p;
     p.in = (const half_t*)in;
     p.in_sN = ind.sN; p.in_sD = ind.sD; p.in_sH = ind.sH; p.in_sW = ind.sW;
-    p.N = N; p.D = D; p.H = H; p.W = W;
+    p.N = N; p.D = D; p.H = H; p.W = W; p.inD = D;
     p.Cin = L.Cin; p.nchunks = (L.Cin + 31) / 32; p.up_shift = up_shift;
     p.KD = L.KD; p.KH = L.KH; p.KW = L.KW; p.PD = L.KD / 2; p.PH = L.KH / 2; p.PW = L.KW / 2;
     p.wgt = L.w; p.Cout_pad = L.Cout_pad; p.Cout = L.Cout;
     p.bias = L.b;
     p.ps_stride = 1;
     c.macs_per_pos = L.macs_per_pos;
+    c.name = L.name.c_str();
     return c;
 }
 
@@ -221,8 +226,9 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
     if (!prefW) { prefW = 16; prefH = BM / 16; }
     set_tile(c.p, BM, prefW, prefH);
-    e->flops += 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
-    return e->run(0, st, [&] { return launch_conv(c.p, c.cfg, c.mode, st); });
+    const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
+    e->flops += fl;
+    return e->run(0, st, [&] { return launch_conv(c.p, c.cfg, c.mode, st); }, c.name, fl);
 }
 
 float* stats_slot(cs_engine* e)
@@ -232,12 +238,12 @@ float* stats_slot(cs_engine* e)
     return p;
 }
 
-int zero_stats(cs_engine* e, hipStream_t st)
+// (mean, rstd) per (n, c) of a [N][P][C] tensor into a fresh slot of the stats pool
+int do_stats(cs_engine* e, const void* x, int is_f32, int B, long P, int C, float** out, hipStream_t st)
 {
-    e->stats_next = 0;
-    hipError_t r = hipMemsetAsync(e->stats_pool, 0, e->stats_slots * e->stats_slot_floats * sizeof(float), st);
-    if (r != hipSuccess) { cs_set_error("memset stats: %s", hipGetErrorString(r)); return -1; }
-    return 0;
+    float* slot = stats_slot(e);
+    *out = slot;
+    return e->run(1, st, [&] { return launch_chan_stats(x, is_f32, B, P, C, 1e-5f, e->stats_part, slot, st); }, "chan_stats");
 }
 
 // ------------------------------------------------------------------------------------------------ F
@@ -265,16 +271,16 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
 
 int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 {
-    TRY(e->run(1, st, [&] { return launch_conv_first(img, e->first_w, e->first_b, e->f_t0, B, IMG, IMG, st); }));
+    TRY(e->run(1, st, [&] { return launch_conv_first(img, e->first_w, e->first_b, e->f_t0, B, IMG, IMG, st); }, "conv_first"));
     e->flops += 2.0 * 3 * 64 * 9 * (double)B * IMG * IMG;
     ConvCall d0 = mk(e->f_down0, e->f_t0, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
     d0.p.act0 = ACT_RELU; d0.p.out0 = nhwc(e->f_t1, 256, 256, 128);
     TRY(go(e, d0, st));
-    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }));
+    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }, "avgpool"));
     ConvCall d1 = mk(e->f_down1, e->f_p0, nhwc(nullptr, 128, 128, 128), B, 1, 128, 128);
     d1.p.act0 = ACT_RELU; d1.p.out0 = nhwc(e->f_t2, 128, 128, 256);
     TRY(go(e, d1, st));
-    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }));
+    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }, "avgpool"));
     *cur = 0;
     ConvCall s = mk(e->f_second, e->f_p1, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);   // 1x1 -> the 32x16 volume
     s.p.out0 = hwdc2(e->vs[0]); s.p.out0_f32 = 1;
@@ -288,10 +294,10 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 // e->dm_deform / e->dm_occ.
 int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st)
 {
-    TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, B, FD, FH, FW, st); }));
-    e->flops += (2.0 * 32 * 4 * VOX + 2.0 * 2272 * 49 * 4096) * B;   // compress + occlusion (launched below)
+    TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, B, FD, FH, FW, st); }, "dm_compress"));
+    e->flops += 2.0 * 32 * 4 * VOX * B;
     // hourglass input lands in channels [32,144) of the level-0 concat buffer (util.py:255-264 cat order)
-    TRY(e->run(1, st, [&] { return launch_dm_sparse(e->dm_comp, kp_d, kp_s, e->dm_l[0] + 32, 144, B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_dm_sparse(e->dm_comp, kp_d, kp_s, e->dm_l[0] + 32, 144, B, FD, FH, FW, st); }, "dm_sparse"));
     static const int cin[5] = {112, 64, 128, 256, 512}, cout[5] = {64, 128, 256, 512, 1024};
     static const int lw[6] = {144, 128, 256, 512, 1024, 1024};   // concat widths per level
     static const int skip_off[6] = {32, 64, 128, 256, 512, 0};   // channel offset of the skip part
@@ -303,7 +309,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         c.p.out0 = dhwc(e->dm_pre, FD, S, S, cout[i]);
         TRY(go(e, c, st));
         TDesc o = dhwc(e->dm_l[i + 1] + skip_off[i + 1], FD, S / 2, S / 2, lw[i + 1]);
-        TRY(e->run(1, st, [&] { return launch_avgpool(e->dm_pre, B, FD, S, S, cout[i], o, st); }));
+        TRY(e->run(1, st, [&] { return launch_avgpool(e->dm_pre, B, FD, S, S, cout[i], o, st); }, "avgpool"));
     }
     for (int i = 0; i < 5; ++i) {       // Decoder: UpBlock3d (util.py:142-147), nearest x(1,2,2) folded into addressing
         const int lv = 5 - i, S = 64 >> (lv - 1), Si = S / 2;
@@ -318,8 +324,13 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 32); m.p.out0_f32 = 1;
     TRY(go(e, m, st));
-    TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, 32, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }));
-    TRY(e->run(1, st, [&] { return launch_dm_occlusion(e->dm_pred, 144, e->occ_w, e->occ_b, e->dm_occ, B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, 32, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
+    // occlusion (dense_motion.py:98-102): depth-collapsing (16 x 7 x 1)-tap conv, 7 horizontal taps as output channels
+    ConvCall oc = mk(e->w_occ, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, 1, 64, 64);
+    oc.p.inD = FD; oc.p.PD = 0; oc.p.PW = 0;
+    oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 16); oc.p.out0_f32 = 1;
+    TRY(go(e, oc, st));
+    TRY(e->run(1, st, [&] { return launch_occ_finish(e->dm_occpart, e->occ_b, e->dm_occ, B, 64, 64, st); }, "occ_finish"));
     return 0;
 }
 
@@ -376,25 +387,24 @@ int run_T(cs_engine* e, int B, int* cur, hipStream_t st)
 // G3d.forward (adaptive_modulate.py:721-733). x: fp32 vs[*cur] + fp16 va[0]; result fp32 in vs[*cur].
 int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
 {
-    const float cnt_inv = 1.f / (float)VOX;
     for (int i = 0; i < 3; ++i) {   // ResBlock3D_stage3_leak (util.py:528-544)
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
         ConvCall c1 = mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
         TRY(go(e, c1, st, 4, 4));
-        float* s1 = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(e->vs[y], 1, B, VOX, 32, s1, st); }));
-        TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, cnt_inv, 1e-5f, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
-                                                       e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }));
+        float* s1;
+        TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s1, st));
+        TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
+                                                       e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }, "norm_act"));
         ConvCall c2 = mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
         TRY(go(e, c2, st, 4, 4));
-        float* s2 = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(e->vs[y], 1, B, VOX, 32, s2, st); }));
+        float* s2;
+        TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s2, st));
         const bool pre = (i == 2 && last_pre);
-        TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s2, cnt_inv, 1e-5f, blk[i].g2, blk[i].b2, e->vs[*cur], 0.01f,
+        TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s2, blk[i].g2, blk[i].b2, e->vs[*cur], 0.01f,
                                                        e->vs[nxt], e->va[0], pre ? last_pre->s : nullptr, pre ? last_pre->t : nullptr,
-                                                       512, pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st); }));
+                                                       512, pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st); }, "norm_act"));
         *cur = nxt;
     }
     return 0;
@@ -432,7 +442,7 @@ int spade_gb(cs_engine* e, const cs_engine::GB& gb, int C, const half_t* actv, i
     c.p.bias = gb.bg; c.p.bias2 = gb.bb;
     const int Sx = S >> xshift;
     c.p.res = nhwc((void*)x, Sx, Sx, C); c.p.res_f32 = 0; c.p.res_shift = xshift;
-    c.p.stats = stats; c.p.stat_cnt_inv = 1.f / (float)(Sx * Sx); c.p.eps = 1e-5f;
+    c.p.stats = stats;
     c.p.act0 = act; c.p.slope0 = 0.2f;
     c.p.out0 = nhwc(out, S, S, C);
     return go(e, c, st);
@@ -440,7 +450,6 @@ int spade_gb(cs_engine* e, const cs_engine::GB& gb, int C, const half_t* actv, i
 
 int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
 {
-    TRY(zero_stats(e, st));
     ConvCall fc = mk(e->g_fc, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
     fc.p.out0 = nhwc(e->g_x[0], 64, 64, 512);
     TRY(go(e, fc, st));
@@ -458,14 +467,14 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     int cx = 0;
     for (int b = 0; b < 6; ++b) {   // SPADEResnetBlock 512->512 @64x64 (util.py:329-344)
         const cs_engine::SpadeBlk& K = e->g_blk[b];
-        float* st0 = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_x[cx], 0, B, 4096, 512, st0, st); }));
+        float* st0;
+        TRY(do_stats(e, e->g_x[cx], 0, B, 4096, 512, &st0, st));
         TRY(spade_gb(e, K.n0, 512, e->g_a64, 1536, (b * 2) * 128, B, 64, e->g_x[cx], 0, st0, ACT_LRELU, e->g_h64, st));
         ConvCall c0 = mk(K.c0, e->g_h64, nhwc(nullptr, 64, 64, 512), B, 1, 64, 64);
         c0.p.out0 = nhwc(e->g_dx64, 64, 64, 512);
         TRY(go(e, c0, st));
-        float* st1 = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_dx64, 0, B, 4096, 512, st1, st); }));
+        float* st1;
+        TRY(do_stats(e, e->g_dx64, 0, B, 4096, 512, &st1, st));
         TRY(spade_gb(e, K.n1, 512, e->g_a64, 1536, (b * 2 + 1) * 128, B, 64, e->g_dx64, 0, st1, ACT_LRELU, e->g_h64, st));
         ConvCall c1 = mk(K.c1, e->g_h64, nhwc(nullptr, 64, 64, 512), B, 1, 64, 64);
         c1.p.res = nhwc(e->g_x[cx], 64, 64, 512);
@@ -477,8 +486,8 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     {
         const cs_engine::SpadeBlk& K = e->g_blk[6];
         const half_t* x = e->g_x[cx];
-        float* sx = stats_slot(e);     // nearest up-sampling leaves per-channel mean / variance unchanged
-        TRY(e->run(1, st, [&] { return launch_chan_stats(x, 0, B, 4096, 512, sx, st); }));
+        float* sx;     // nearest up-sampling leaves per-channel mean / variance unchanged
+        TRY(do_stats(e, x, 0, B, 4096, 512, &sx, st));
         TRY(spade_gb(e, K.ns, 512, e->g_a128, 384, 256, B, 128, x, 1, sx, ACT_NONE, e->g_h128, st));
         ConvCall cs = mk(K.cs, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
         cs.p.out0 = nhwc(e->g_xs128, 128, 128, 256);
@@ -487,8 +496,8 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
         ConvCall c0 = mk(K.c0, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
         c0.p.out0 = nhwc(e->g_dx128, 128, 128, 256);
         TRY(go(e, c0, st));
-        float* s1 = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_dx128, 0, B, 16384, 256, s1, st); }));
+        float* s1;
+        TRY(do_stats(e, e->g_dx128, 0, B, 16384, 256, &s1, st));
         TRY(spade_gb(e, K.n1, 256, e->g_a128, 384, 128, B, 128, e->g_dx128, 0, s1, ACT_LRELU, e->g_h1_128, st));
         ConvCall c1 = mk(K.c1, e->g_h1_128, nhwc(nullptr, 128, 128, 256), B, 1, 128, 128);
         c1.p.res = nhwc(e->g_xs128, 128, 128, 256);
@@ -499,8 +508,8 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     {
         const cs_engine::SpadeBlk& K = e->g_blk[7];
         const half_t* x = e->g_o128;
-        float* sx = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(x, 0, B, 16384, 256, sx, st); }));
+        float* sx;
+        TRY(do_stats(e, x, 0, B, 16384, 256, &sx, st));
         TRY(spade_gb(e, K.ns, 256, e->g_a256, 384, 256, B, 256, x, 1, sx, ACT_NONE, e->g_h256, st));
         ConvCall cs = mk(K.cs, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
         cs.p.out0 = nhwc(e->g_xs256, 256, 256, 64);
@@ -509,8 +518,8 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
         ConvCall c0 = mk(K.c0, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
         c0.p.out0 = nhwc(e->g_dx256, 256, 256, 64);
         TRY(go(e, c0, st));
-        float* s1 = stats_slot(e);
-        TRY(e->run(1, st, [&] { return launch_chan_stats(e->g_dx256, 0, B, 65536, 64, s1, st); }));
+        float* s1;
+        TRY(do_stats(e, e->g_dx256, 0, B, 65536, 64, &s1, st));
         TRY(spade_gb(e, K.n1, 64, e->g_a256, 384, 128, B, 256, e->g_dx256, 0, s1, ACT_LRELU, e->g_h1_256, st));
         ConvCall c1 = mk(K.c1, e->g_h1_256, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
         c1.p.res = nhwc(e->g_xs256, 256, 256, 64);
@@ -543,11 +552,11 @@ int copy_dd(void* dst, const void* src, size_t bytes, hipStream_t st)
 
 int to_hwdc(cs_engine* e, int B, const float* f, float* out32, half_t* out16, hipStream_t st)
 {
-    return e->run(1, st, [&] { return launch_ncdhw_to_hwdc(f, out32, out16, nullptr, nullptr, ACT_NONE, 0.f, B, FC, FD, FH, FW, st); });
+    return e->run(1, st, [&] { return launch_ncdhw_to_hwdc(f, out32, out16, nullptr, nullptr, ACT_NONE, 0.f, B, FC, FD, FH, FW, st); }, "ncdhw_to_hwdc");
 }
 int from_hwdc(cs_engine* e, int B, const float* in, float* out, hipStream_t st)
 {
-    return e->run(1, st, [&] { return launch_hwdc_to_ncdhw(in, out, B, FC, FD, FH, FW, st); });
+    return e->run(1, st, [&] { return launch_hwdc_to_ncdhw(in, out, B, FC, FD, FH, FW, st); }, "hwdc_to_ncdhw");
 }
 
 }  // namespace
@@ -579,6 +588,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     A(tmask, B * 4096 * 4); A(style, 14 * 512);
     e->stats_slots = 48; e->stats_slot_floats = B * 512 * 2;
     A(stats_pool, e->stats_slots * e->stats_slot_floats);
+    A(stats_part, B * 262144); A(dm_occpart, B * 4096 * 16);
     for (int i = 0; i < 2; ++i) A(g_x[i], B * 4096 * 512);
     A(g_h64, B * 4096 * 512); A(g_dx64, B * 4096 * 512); A(g_a64, B * 4096 * 1536);
     A(g_a128, B * 16384 * 384); A(g_a256, B * 65536 * 384);
@@ -650,8 +660,8 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     }
     TRY(get_conv(e, "W.tail", 144, 192, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.mask", 144, 32, 32, 7, 7, 7, 32, 142.0 * 22 * 343, &e->w_mask));
-    { const void* p; TRY(need(e, "W.occ.w", (size_t)16 * 49 * 144 * 2, &p)); e->occ_w = (const half_t*)p;
-      const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
+    TRY(get_conv(e, "W.occp", 144, 16, 16, 16, 7, 1, 0, 2272.0 * 49, &e->w_occ));
+    { const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
       CS_CHECK_HIP(hipMemcpy(&e->occ_b, b->p, 4, hipMemcpyDeviceToHost)); }
     TRY(get_conv(e, "W.third", 512, 256, 256, 1, 3, 3, 256, 512.0 * 256 * 9, &e->w_third));
     TRY(get_conv(e, "W.fourth", 256, 256, 256, 1, 1, 1, 256, 256.0 * 256, &e->w_fourth));
@@ -728,8 +738,8 @@ extern "C" int cs_set_identity(cs_engine* e, int slot, const float* id, void* st
     CS_CHECK_HIP(hipSetDevice(e->dev));
     for (int i = 0; i < 14; ++i) {
         TLayer& L = e->t_l[i];
-        TRY(e->run(1, st, [&] { return launch_t_style(id, L.fc, e->style + i * 512, 1, st); }));
-        TRY(e->run(1, st, [&] { return launch_t_modulate(L.raw, e->style + i * 512, L.wmut, i, st); }));
+        TRY(e->run(1, st, [&] { return launch_t_style(id, L.fc, e->style + i * 512, 1, st); }, "t_style"));
+        TRY(e->run(1, st, [&] { return launch_t_modulate(L.raw, e->style + i * 512, L.wmut, i, st); }, "t_modulate"));
     }
     e->identity_set = true;
     return 0;
@@ -751,7 +761,7 @@ extern "C" int cs_warp(cs_engine* e, int B, const float* f, const float* kp_sour
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
     TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, e->vs[1], nullptr, B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, e->vs[1], nullptr, B, FD, FH, FW, st); }, "grid_sample"));
     TRY(from_hwdc(e, B, e->vs[1], f_out, st));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
     return 0;
@@ -763,7 +773,7 @@ extern "C" int cs_warp_out(cs_engine* e, int B, const float* f, const float* occ
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, nullptr, e->va[0], st));
     TRY(run_warp_out(e, B, e->va[0], occ, st));
-    return e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); });
+    return e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }, "nhwc16_to_nchw");
 }
 
 extern "C" int cs_swap(cs_engine* e, int slot, int B, const float* f, float* f_out, void* stream)
@@ -783,7 +793,6 @@ extern "C" int cs_refine(cs_engine* e, int B, const float* f, float* f_out, void
     hipStream_t st = (hipStream_t)stream;
     int cur = 0;
     TRY(to_hwdc(e, B, f, e->vs[0], e->va[0], st));
-    TRY(zero_stats(e, st));
     TRY(run_R(e, B, &cur, st));
     return from_hwdc(e, B, e->vs[cur], f_out, st);
 }
@@ -795,9 +804,9 @@ extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float*
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
     TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
-    if (seg_out) TRY(e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }));
+    if (seg_out) TRY(e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }, "nhwc16_to_nchw"));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
     if (deformation_out) TRY(copy_dd(deformation_out, e->dm_deform, (size_t)B * VOX * 3 * 4, st));
     return 0;
@@ -807,7 +816,7 @@ extern "C" int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img
 {
     TRY(check(e, B));
     hipStream_t st = (hipStream_t)stream;
-    TRY(e->run(1, st, [&] { return launch_nchw_to_nhwc16(seg, e->seg16, B, 256, 4096, st); }));
+    TRY(e->run(1, st, [&] { return launch_nchw_to_nhwc16(seg, e->seg16, B, 256, 4096, st); }, "nchw_to_nhwc16"));
     return run_G(e, B, e->seg16, img_out, st);
 }
 
@@ -815,7 +824,7 @@ extern "C" int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, i
 {
     if (!e) { cs_set_error("null engine"); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    return e->run(1, st, [&] { return launch_pack_u8(img, out, B, 3, H, W, st); });
+    return e->run(1, st, [&] { return launch_pack_u8(img, out, B, 3, H, W, st); }, "pack_u8");
 }
 
 extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
@@ -829,7 +838,7 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
     // :244 warp(f_s, kp_source = x_t, kp_driving = x_can)
     TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_can, /*kp_s*/ x_t, nullptr, st));
     const int nxt = (cur + 1) % 3;
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, e->vs[nxt], e->va[0], B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, e->vs[nxt], e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
     cur = nxt;
     // the first warp's occlusion map is reused by the debug decodes (:248,:257); keep a copy in tmask-free storage
     float* occ1 = e->img_b;   // B*4096 floats fit easily
@@ -843,15 +852,14 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
         TRY(run_warp_out(e, B, e->va[0], occ1, st));
         TRY(run_G(e, B, e->seg16, swap_can, st));
     }
-    TRY(zero_stats(e, st));
     TRY(run_R(e, B, &cur, st));                                                             // :262
     // :263 warp_decode(f, kp_source = x_can, kp_driving = x_t)
     TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_t, /*kp_s*/ x_can, nullptr, st));
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }));
+    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     float* dst = out_f32 ? out_f32 : e->img_a;
     TRY(run_G(e, B, e->seg16, dst, st));
-    if (out_u8) TRY(e->run(1, st, [&] { return launch_pack_u8(dst, out_u8, B, 3, 512, 512, st); }));
+    if (out_u8) TRY(e->run(1, st, [&] { return launch_pack_u8(dst, out_u8, B, 3, 512, 512, st); }, "pack_u8"));
     return 0;
 }
 
@@ -867,11 +875,16 @@ extern "C" int cs_profile_end(cs_engine* e, double ms[2], long counts[2], double
     if (!e) { cs_set_error("null engine"); return -1; }
     CS_CHECK_HIP(hipDeviceSynchronize());
     ms[0] = ms[1] = 0; counts[0] = counts[1] = 0;
+    FILE* csv = nullptr;
+    if (const char* path = getenv("CANONSWAP_PROFILE_CSV")) csv = fopen(path, "w");
+    if (csv) fprintf(csv, "family,label,ms,gflop\n");
     for (auto& r : e->recs) {
         float t = 0;
         CS_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
         ms[r.fam] += t; counts[r.fam]++;
+        if (csv) fprintf(csv, "%d,%s,%.5f,%.4f\n", r.fam, r.label.c_str(), t, r.flops / 1e9);
     }
+    if (csv) fclose(csv);
     if (flops) *flops = e->flops;
     e->prof = false; e->recs.clear(); e->evnext = 0;
     return 0;
@@ -884,7 +897,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     memset(&c.p, 0, sizeof(c.p));
     ConvParams& p = c.p;
     p.in = (const half_t*)d->in; p.in_sN = d->in_sN; p.in_sD = d->in_sD; p.in_sH = d->in_sH; p.in_sW = d->in_sW;
-    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.nchunks = (d->Cin + 31) / 32; p.up_shift = d->up_shift;
+    p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.inD = d->D; p.Cin = d->Cin; p.nchunks = (d->Cin + 31) / 32; p.up_shift = d->up_shift;
     p.KD = d->KD; p.KH = d->KH; p.KW = d->KW; p.PD = d->KD / 2; p.PH = d->KH / 2; p.PW = d->KW / 2;
     p.wgt = (const half_t*)d->wgt; p.Cout_pad = d->Cout_pad; p.Cout = d->Cout;
     p.bias = d->bias; p.bias2 = d->bias2; p.act0 = d->act0; p.slope0 = d->slope0;
@@ -893,7 +906,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     p.out0 = td(d->out0, d->out0_sN, d->out0_sD, d->out0_sH, d->out0_sW); p.out0_f32 = d->out0_f32;
     p.s2 = d->s2; p.t2 = d->t2; p.act1 = d->act1; p.slope1 = d->slope1;
     p.out1 = td(d->out1, d->out1_sN, d->out1_sD, d->out1_sH, d->out1_sW);
-    p.stats = d->stats; p.stat_cnt_inv = d->stat_cnt_inv; p.eps = d->eps;
+    p.stats = d->stats;
     c.mode = d->mode;
     c.cfg = d->cfg >= 0 ? d->cfg : pick_cfg(p.Cout_pad);
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
@@ -907,7 +920,9 @@ extern "C" int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, floa
     return launch_grid_sample(in_hwdc, grid, out32, (half_t*)out16, N, D, H, W, (hipStream_t)stream);
 }
 
-extern "C" int cs_op_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, void* stream)
+extern "C" long cs_op_chan_stats_partial_floats(int N, long P, int C) { return chan_stats_partial_floats(N, P, C); }
+
+extern "C" int cs_op_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, void* stream)
 {
-    return launch_chan_stats(x, is_f32, N, P, C, stats, (hipStream_t)stream);
+    return launch_chan_stats(x, is_f32, N, P, C, eps, partials, stats, (hipStream_t)stream);
 }

@@ -256,50 +256,28 @@ int launch_dm_softmax(const float* logits, int lstride, const float* kp_d, const
     return 0;
 }
 
-// occlusion map: conv2d 7x7 over the (c,d)-flattened prediction -> 1 channel, sigmoid
-// (dense_motion.py:25,98-102). N_out = 1, so this is a reduction, not MFMA work.
-// pred: fp16 [N][D][H][W][C]; w: fp16 [D][7][7][C]; occ: fp32 [N][H][W].
-// workgroup = 16 output columns x 16 depth slices; LDS reduction over depth.
-__global__ void __launch_bounds__(256) dm_occlusion_kernel(const half_t* __restrict__ pred, int C, const half_t* __restrict__ w,
-                                                           float bias, float* __restrict__ occ, int N, int D, int H, int W)
+// occlusion map, second half (dense_motion.py:98-102). The 7x7 conv over the (c,d)-flattened prediction is run
+// on the MFMA conv kernel as a depth-collapsing (16 x 7 x 1)-tap conv whose 7 output channels are the 7
+// horizontal taps: part[n][y][xin][kx] = sum_{d,ky,c} pred[d][y+ky-3][xin][c] * w[c*16+d][ky][kx].
+// This kernel finishes: occ[y][x] = sigmoid(bias + sum_kx part[y][x+kx-3][kx]).
+__global__ void __launch_bounds__(256) occ_finish_kernel(const float* __restrict__ part, float bias, float* __restrict__ occ, int N, int H, int W)
 {
-    __shared__ float red[256];
-    const int xl = threadIdx.x & 15, d = threadIdx.x >> 4;
-    const int xt = blockIdx.x % (W / 16);
-    const int y = (blockIdx.x / (W / 16)) % H;
-    const int n = blockIdx.x / ((W / 16) * H);
-    const int x = xt * 16 + xl;
-    const int C8 = C >> 3;
-    float acc = 0.f;
-    for (int ky = 0; ky < 7; ++ky) {
-        const int yy = y + ky - 3;
-        if ((unsigned)yy >= (unsigned)H) continue;
-        for (int kx = 0; kx < 7; ++kx) {
-            const int xx = x + kx - 3;
-            if ((unsigned)xx >= (unsigned)W) continue;
-            const h8_t* a = (const h8_t*)(pred + ((((long)n * D + d) * H + yy) * W + xx) * C);
-            const h8_t* b = (const h8_t*)(w + ((long)(d * 7 + ky) * 7 + kx) * C);
-            for (int c = 0; c < C8; ++c) {
-                const h8_t av = a[c], bv = b[c];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W) return;
+    const int x = i % W;
+    float s = bias;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc = fmaf((float)av[j], (float)bv[j], acc);
-            }
-        }
+    for (int kx = 0; kx < 7; ++kx) {
+        const int xx = x + kx - 3;
+        if ((unsigned)xx < (unsigned)W) s += part[(i + kx - 3) * 16 + kx];
     }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (d == 0) {
-        float s = bias;
-        for (int j = 0; j < D; ++j) s += red[j * 16 + xl];
-        occ[((long)n * H + y) * W + x] = 1.f / (1.f + __expf(-s));
-    }
+    occ[i] = 1.f / (1.f + __expf(-s));
 }
 
-int launch_dm_occlusion(const half_t* pred, int C, const half_t* w, float bias, float* occ, int N, int D, int H, int W, hipStream_t st)
+int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st)
 {
-    if (D != 16 || W % 16) { cs_set_error("dm_occlusion: needs D == 16 and W %% 16 == 0"); return -1; }
-    hipLaunchKernelGGL(dm_occlusion_kernel, dim3((unsigned)((long)N * H * (W / 16))), dim3(256), 0, st, pred, C, w, bias, occ, N, D, H, W);
-    LAUNCH_CHECK("dm_occlusion");
+    hipLaunchKernelGGL(occ_finish_kernel, dim3(cdiv((long)N * H * W, 256)), dim3(256), 0, st, part, bias, occ, N, H, W);
+    LAUNCH_CHECK("occ_finish");
     return 0;
 }
 
@@ -354,11 +332,13 @@ int launch_grid_sample(const float* in, const float* grid, float* out32, half_t*
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-(n, channel) sum / sum of squares over P positions of a [N][P][C] tensor
-// (InstanceNorm2d util.py:286,296; GroupNorm(32,32) util.py:521-523). stats must be zeroed first.
+// per-(n, channel) mean and 1/sqrt(var+eps) over P positions of a [N][P][C] tensor (biased variance)
+// (InstanceNorm2d util.py:286,296; GroupNorm(32,32) util.py:521-523). Two deterministic passes: fixed-order
+// partial sums per workgroup, then a fixed-order fp64 finish -- no atomics, so results do not depend on
+// scheduling or on the batch size.
 // ------------------------------------------------------------------------------------------------
 template <bool F32>
-__global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict__ xin, long P, int C, int ppb, float* __restrict__ stats)
+__global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict__ xin, long P, int C, int ppb, float* __restrict__ partials)
 {
     __shared__ float red[256 * 8];
     const int G = C >> 2;            // channel groups of 4
@@ -386,24 +366,46 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict_
         for (int j = 1; j < PL; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s[r] += red[(j * G + g) * 8 + r]; ss[r] += red[(j * G + g) * 8 + 4 + r]; }
+        float* o = partials + (((long)n * gridDim.x + blockIdx.x) * C + g * 4) * 2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            atomicAdd(stats + ((long)n * C + g * 4 + r) * 2, s[r]);
-            atomicAdd(stats + ((long)n * C + g * 4 + r) * 2 + 1, ss[r]);
-        }
+        for (int r = 0; r < 4; ++r) { o[r * 2] = s[r]; o[r * 2 + 1] = ss[r]; }
     }
 }
 
-int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, hipStream_t st)
+__global__ void __launch_bounds__(256) chan_stats_finish_kernel(const float* __restrict__ partials, int nblk, int C, int NC, double cnt_inv,
+                                                                float eps, float* __restrict__ stats)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;     // (n, c)
+    if (i >= NC) return;
+    const int n = i / C, c = i % C;
+    double s = 0, ss = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* q = partials + (((long)n * nblk + b) * C + c) * 2;
+        s += q[0]; ss += q[1];
+    }
+    const double mean = s * cnt_inv;
+    double var = ss * cnt_inv - mean * mean;
+    if (var < 0) var = 0;
+    stats[(long)i * 2] = (float)mean;
+    stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+static inline int stats_ppb(long P, int C) { const int PL = 256 / (C / 4); return P <= 16384 ? PL * 16 : PL * 32; }
+
+long chan_stats_partial_floats(int N, long P, int C) { return (long)N * cdiv(P, stats_ppb(P, C)) * C * 2; }
+
+int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st)
 {
     const int G = C / 4;
     if (C % 4 || G > 256 || 256 % G) { cs_set_error("chan_stats: unsupported C=%d", C); return -1; }
-    const int PL = 256 / G;
-    const int ppb = P <= 16384 ? PL * 16 : PL * 32;   // 16-32 positions per thread, many workgroups
+    const int ppb = stats_ppb(P, C);
     dim3 grid(cdiv(P, ppb), (unsigned)N);
-    if (is_f32) hipLaunchKernelGGL(chan_stats_kernel<true>, grid, dim3(256), 0, st, x, P, C, ppb, stats);
-    else hipLaunchKernelGGL(chan_stats_kernel<false>, grid, dim3(256), 0, st, x, P, C, ppb, stats);
+    if (is_f32) hipLaunchKernelGGL(chan_stats_kernel<true>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
+    else hipLaunchKernelGGL(chan_stats_kernel<false>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     LAUNCH_CHECK("chan_stats");
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
+                       1.0 / (double)P, eps, stats);
+    LAUNCH_CHECK("chan_stats_finish");
     return 0;
 }
 
@@ -416,8 +418,8 @@ __device__ __forceinline__ float act_f(float v, int act, float slope)
 
 // GroupNorm(32,32) apply + optional residual + LeakyReLU (util.py:531-540), on fp32 HWDC volumes.
 // out32 = lrelu(gn(y) [+ res]); out16 = act2(out32 * s2[i % period2] + t2[i % period2]) (next conv's input).
-__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ y, const float* __restrict__ stats, float cnt_inv,
-                                                       float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ res, float slope, float* __restrict__ out32,
                                                        half_t* __restrict__ out16, const float* __restrict__ s2,
                                                        const float* __restrict__ t2, int period2, int act2, float slope2, long per_n,
@@ -436,9 +438,7 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float* st = stats + ((long)n * 32 + c + r) * 2;
-        const float mean = st[0] * cnt_inv;
-        const float var = fmaxf(st[1] * cnt_inv - mean * mean, 0.f);
-        float a = (v[r] - mean) * rsqrtf(var + eps) * gamma[c + r] + beta[c + r] + rr[r];
+        float a = (v[r] - st[0]) * st[1] * gamma[c + r] + beta[c + r] + rr[r];
         a = a > 0.f ? a : a * slope;
         v[r] = a;
         if (s2) { const int j = (int)((i + r) % period2); a = a * s2[j] + t2[j]; }
@@ -448,12 +448,12 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     if (out16) *(h4_t*)(out16 + i) = o16;
 }
 
-int launch_norm_act(const float* y, const float* stats, float cnt_inv, float eps, const float* gamma, const float* beta,
+int launch_norm_act(const float* y, const float* stats, const float* gamma, const float* beta,
                     const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
                     int act2, float slope2, int N, long per_n, hipStream_t st)
 {
     const long total4 = (long)N * per_n / 4;
-    hipLaunchKernelGGL(norm_act_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, y, stats, cnt_inv, eps, gamma, beta, res, slope,
+    hipLaunchKernelGGL(norm_act_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, y, stats, gamma, beta, res, slope,
                        out32, out16, s2, t2, period2, act2, slope2, per_n, total4);
     LAUNCH_CHECK("norm_act");
     return 0;

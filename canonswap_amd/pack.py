@@ -136,9 +136,9 @@ def _pack_W(out, sd):
     out["W.mask.w"] = pack_conv(sd[p + ".mask.weight"], 32)
     out["W.mask.b"] = _f32(_pad(sd[p + ".mask.bias"], 32))
     wo = sd[p + ".occlusion.weight"].reshape(142, 16, 7, 7)          # channel j = c*16 + d (dense_motion.py:100)
-    occ = np.zeros((16, 7, 7, 144), np.float32)
-    occ[..., :142] = wo.transpose(1, 2, 3, 0)
-    out["W.occ.w"] = np.ascontiguousarray(occ.astype(np.float16))
+    # run on the MFMA conv as a depth-collapsing (KD=16, KH=7, KW=1) conv whose 7 output channels are the 7
+    # horizontal taps kx (finished by occ_finish_kernel): w[kx][c][d][ky][0] = W_occ[0][c*16+d][ky][kx]
+    out["W.occp.w"] = pack_conv(wo.transpose(3, 0, 1, 2)[..., None], 16)
     out["W.occ.b"] = _f32(sd[p + ".occlusion.bias"].reshape(1))
     s, t = bn_affine(sd, "third.norm")
     w, b = fold_conv_bn(sd["third.conv.weight"][:, MEM2REF], sd["third.conv.bias"], s, t)

@@ -83,7 +83,7 @@ typedef struct cs_conv_desc {
     void* out0; int out0_f32; long out0_sN, out0_sD, out0_sH, out0_sW;
     const float* s2; const float* t2; int act1; float slope1;
     void* out1; long out1_sN, out1_sD, out1_sH, out1_sW;
-    const float* stats; float stat_cnt_inv; float eps;
+    const float* stats;       /* SPADE: [N][C][2] = (mean, 1/sqrt(var+eps)) from cs_op_chan_stats */
     int mode;                 /* 0 std, 1 T blend, 2 SPADE, 3 pixel-shuffle + sigmoid */
     int cfg;                  /* -1 auto, else tile configuration */
     int tile_w, tile_h;       /* 0 = auto */
@@ -91,7 +91,9 @@ typedef struct cs_conv_desc {
 int cs_op_conv(const cs_conv_desc* d, void* stream);
 int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,
                         void* stream);
-int cs_op_chan_stats(const void* x, int is_f32, int N, long P, int C, float* stats, void* stream);
+/* per-(n,c) mean and 1/sqrt(var+eps) of a [N][P][C] tensor; partials: scratch of cs_op_chan_stats_partial_floats floats */
+long cs_op_chan_stats_partial_floats(int N, long P, int C);
+int cs_op_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, void* stream);
 
 #ifdef __cplusplus
 }

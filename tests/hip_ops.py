@@ -21,7 +21,7 @@ def strides_cl(t):
 
 def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0="none", slope0=0.0, res=None, res_shift=0,
          pixscale=None, ps_stride=1, out0=None, s2=None, t2=None, act1="none", slope1=0.0, out1=None, stats=None,
-         stat_cnt_inv=0.0, eps=1e-5, mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None):
+         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None):
     """x: [N, D, H, W, C] fp16 view (C contiguous). out0/out1/res: 5-D channels-last views. k = (KD, KH, KW)."""
     lib = _lib.load()
     d = _lib.ConvDesc()
@@ -53,7 +53,6 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
         d.out1 = out1.data_ptr()
         d.out1_sN, d.out1_sD, d.out1_sH, d.out1_sW = strides_cl(out1)
     d.stats = 0 if stats is None else stats.data_ptr()
-    d.stat_cnt_inv, d.eps = stat_cnt_inv, eps
     d.mode, d.cfg = mode, cfg
     d.tile_w, d.tile_h = tile
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -74,13 +73,14 @@ def grid_sample(inp_hwdc, grid):
     return out32, out16
 
 
-def chan_stats(x):
-    """x: [N, P, C] fp16/fp32 contiguous -> [N, C, 2]."""
+def chan_stats(x, eps=1e-5):
+    """x: [N, P, C] fp16/fp32 contiguous -> [N, C, 2] = (mean, 1/sqrt(var + eps)), biased variance."""
     lib = _lib.load()
     N, P, Cc = x.shape
     stats = torch.zeros(N, Cc, 2, dtype=torch.float32, device=x.device)
+    part = torch.empty(lib.cs_op_chan_stats_partial_floats(N, P, Cc), dtype=torch.float32, device=x.device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.cs_op_chan_stats(_p(x), int(x.dtype == torch.float32), N, P, Cc, _p(stats), st), "cs_op_chan_stats")
+    _lib.check(lib.cs_op_chan_stats(_p(x), int(x.dtype == torch.float32), N, P, Cc, eps, _p(part), _p(stats), st), "cs_op_chan_stats")
     return stats
 
 

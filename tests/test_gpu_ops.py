@@ -164,7 +164,7 @@ def test_conv_spade(xshift):
     wp = torch.from_numpy(pack.pack_conv(pack.interleave16(wg.numpy(), wb.numpy()), 128)).to(DEV)
     out = torch.zeros(N, 1, S, S, Cc, dtype=torch.float16, device=DEV)
     ops.conv(_to_cl(actv).to(DEV), wp, 128, Cc, (1, 3, 3), bias=bg.to(DEV), bias2=bb.to(DEV), res=xd.unsqueeze(1), res_shift=xshift,
-             stats=stats, stat_cnt_inv=1.0 / (Sx * Sx), eps=1e-5, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=0)
+             stats=stats, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=0)
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
 
@@ -206,6 +206,8 @@ def test_chan_stats(dtype, Cc, P):
     r = _rng(18)
     x = (_randn(r, 2, P, Cc) + 0.3).to(dtype)
     st = ops.chan_stats(x.to(DEV)).cpu()
+    st2 = ops.chan_stats(x.to(DEV)).cpu()
+    assert torch.equal(st, st2)                                         # deterministic (no atomics)
     xf = x.double()
-    assert torch.allclose(st[..., 0].double(), xf.sum(1), rtol=1e-4, atol=1e-2)
-    assert torch.allclose(st[..., 1].double(), (xf * xf).sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(st[..., 0].double(), xf.mean(1), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(st[..., 1].double(), 1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5), rtol=1e-4)

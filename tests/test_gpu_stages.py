@@ -94,7 +94,8 @@ def test_swap_frames_psnr_and_debug(swapper, case):
     u8 = r["out_u8"].cpu().numpy()
     assert u8.shape == (2, 512, 512, 3) and u8.dtype == np.uint8
     assert np.array_equal(u8, O.parse_output(r["out"]))                     # device pack == reference parse_output
-    assert np.abs(u8.astype(np.int32) - O.parse_output(ref["out"]).astype(np.int32)).max() <= 3
+    du8 = u8.astype(np.float64) - O.parse_output(ref["out"]).astype(np.float64)    # both truncated to 8 bits
+    assert 10 * np.log10(255.0 ** 2 / np.mean(du8 ** 2)) >= 48.0 and np.abs(du8).mean() < 0.6
     assert np.array_equal(swapper.parse_output(r["out"]), u8)
 
 
@@ -110,14 +111,14 @@ def test_golden_full_size_frame(swapper, golden):
 
 
 def test_batch_independence_and_determinism(swapper, case):
-    """Frames are independent units (no temporal state): B=1 twice == B=2; the same call twice is stable."""
+    """Frames are independent units (no temporal state): B=1 twice == B=2, bit for bit; reruns are bit-identical."""
     args, idv, _ = case
     a = swapper.swap_frames(args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), idv.cuda())["out"].clone()
     b0 = swapper.swap_frames(args["img"][:1].cuda(), args["x_t"][:1].cuda(), args["x_can"][:1].cuda(), idv.cuda())["out"].clone()
     b1 = swapper.swap_frames(args["img"][1:].cuda(), args["x_t"][1:].cuda(), args["x_can"][1:].cuda(), idv.cuda())["out"].clone()
-    assert (a[0] - b0[0]).abs().max() < 2e-3 and (a[1] - b1[0]).abs().max() < 2e-3
+    assert torch.equal(a[0], b0[0]) and torch.equal(a[1], b1[0])       # no atomics, fixed reduction orders
     a2 = swapper.swap_frames(args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), idv.cuda())["out"]
-    assert (a - a2).abs().max() < 2e-3
+    assert torch.equal(a, a2)
 
 
 def test_identity_changes_output(swapper, case):

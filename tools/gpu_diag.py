@@ -75,7 +75,10 @@ def main():
         for _ in range(n):
             eng.swap_frames(*ga, idv.cuda(), out_f32=out)
         torch.cuda.synchronize(); dt = (time.time() - t) / n
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        os.environ["CANONSWAP_PROFILE_CSV"] = os.path.join(ROOT, "gpurun_out", "layers_b%d.csv" % B)
         eng.profile_begin(); eng.swap_frames(*ga, idv.cuda(), out_f32=out); p = eng.profile_end()
+        del os.environ["CANONSWAP_PROFILE_CSV"]
         print("B=%d: %.2f ms/step  %.1f frames/s | conv %.2f ms (%d launches, %.1f TFLOP/s)  other %.2f ms (%d launches)  algo GFLOP/frame %.1f"
               % (B, dt * 1e3, B / dt, p["conv_ms"], p["conv_launches"], p["conv_flops"] / p["conv_ms"] / 1e9, p["other_ms"],
                  p["other_launches"], p["conv_flops"] / B / 1e9))
