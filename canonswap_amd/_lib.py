@@ -10,8 +10,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hip", "kernels.hip", "engine.hip")]
-HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(os.path.dirname(HERE), "include", "canonswap_hip.h")]
+SOURCES = [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hip", "conv_halo.hip", "kernels.hip", "engine.hip")]
+HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "conv_epilogue.h"), os.path.join(os.path.dirname(HERE), "include", "canonswap_hip.h")]
 LIB_PATH = os.path.join(HERE, "libcanonswap_hip.so")
 ABI_SYMBOLS = [
     "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity",
@@ -50,7 +50,7 @@ class ConvDesc(C.Structure):
         ("s2", C.c_void_p), ("t2", C.c_void_p), ("act1", C.c_int), ("slope1", C.c_float),
         ("out1", C.c_void_p), ("out1_sN", C.c_long), ("out1_sD", C.c_long), ("out1_sH", C.c_long), ("out1_sW", C.c_long),
         ("stats", C.c_void_p),
-        ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int),
+        ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int),
     ]
 
 

@@ -12,6 +12,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
 enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3 };
 // tile configurations of conv_igemm (pixels x channels per 256-thread workgroup)
 enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
+// tile configurations of conv_halo
+enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 13, CFG_H_128x16 = 14, CFG_H_256x16 = 15 };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {
@@ -71,6 +73,7 @@ void cs_set_error(const char* fmt, ...);
 
 // ---- kernel launchers (conv_igemm.hip, kernels.hip); all asynchronous on `st`
 int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);
+int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st);
 
 int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);
 int launch_avgpool(const half_t* in, int N, int D, int H, int W, int C, TDesc out, hipStream_t st);

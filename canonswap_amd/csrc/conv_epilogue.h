@@ -1,0 +1,114 @@
+// Shared epilogue of the gfx950 conv kernels (conv_igemm.hip, conv_halo.hip).
+// Accumulator layout (v_mfma_f32_16x16x32_f16 with weights as the A operand): acc[ci][pi][r] is
+// channel (16-block ci, row l4*4 + r) of position (16-block pi, column l15).
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ void load4(const TDesc& t, int is_f32, long off, float v[4])
+{
+    if (is_f32) {
+        const float4 x = *(const float4*)((const float*)t.p + off);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+        const h4_t x = *(const h4_t*)((const half_t*)t.p + off);
+        v[0] = (float)x[0]; v[1] = (float)x[1]; v[2] = (float)x[2]; v[3] = (float)x[3];
+    }
+}
+
+__device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, const float v[4])
+{
+    if (is_f32) {
+        *(float4*)((float*)t.p + off) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        h4_t x;
+        x[0] = (half_t)v[0]; x[1] = (half_t)v[1]; x[2] = (half_t)v[2]; x[3] = (half_t)v[3];
+        *(h4_t*)((half_t*)t.p + off) = x;
+    }
+}
+
+
+// Expects in scope: p, acc, n0, tw, th, td, tn, lgS, mW, mH, mD, wpx, wch, l15, l4 and the template constants
+// WPX, WCH, BM, MODE.
+#define CONV_EPILOGUE() \
+    constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
+_Pragma("unroll") \
+    for (int pi = 0; pi < WPX; ++pi) { \
+        int m = wpx * WPX * 16 + pi * 16 + l15; \
+        const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
+        const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
+        const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD; \
+        const int n = tn * (BM >> lgS) + m; \
+        if (n >= p.N) continue; \
+        float ps = 1.f; \
+        if (p.pixscale) ps = p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
+_Pragma("unroll") \
+        for (int ci = 0; ci < WCH; ci += CSTEP) { \
+            const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
+            const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+            if (cb >= p.Cout) continue; \
+            float v[4]; \
+            if (MODE == MODE_TBLEND) { \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) \
+                    v[r] = ps * (acc[ci + CSTEP - 1][pi][r] + p.bias[cb + r]) + (1.f - ps) * acc[ci][pi][r]; \
+            } else if (MODE == MODE_SPADE) { \
+                float x[4]; \
+                const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> p.res_shift) * p.res.sH + \
+                                (long)(w >> p.res_shift) * p.res.sW + cb; \
+                load4(p.res, p.res_f32, xo, x); \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) { \
+                    const float* st = p.stats + ((long)n * p.Cout + cb + r) * 2; \
+                    const float g = acc[ci][pi][r] + p.bias[cb + r]; \
+                    const float b = acc[ci + CSTEP - 1][pi][r] + p.bias2[cb + r]; \
+                    v[r] = (x[r] - st[0]) * st[1] * (1.f + g) + b; \
+                } \
+            } else { \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) v[r] = acc[ci][pi][r] + (p.bias ? p.bias[cb + r] : 0.f); \
+            } \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act0, p.slope0); \
+            if (MODE == MODE_PIXSHUF) { \
+                const int c = cb >> 2; \
+                if (c < 3) { \
+                    float* o = (float*)p.out0.p; \
+                    const long W2 = 2L * p.W, H2 = 2L * p.H; \
+                    const long base = (((long)n * 3 + c) * H2 + 2 * h) * W2 + 2 * w; \
+                    *(float2*)(o + base) = make_float2(v[0], v[1]); \
+                    *(float2*)(o + base + W2) = make_float2(v[2], v[3]); \
+                } \
+                continue; \
+            } \
+            if (MODE != MODE_SPADE && p.res.p) { \
+                float rr[4]; \
+                load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)h * p.res.sH + (long)w * p.res.sW + cb, rr); \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
+            } \
+            if (MODE == MODE_STD && p.pixscale) { \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) v[r] *= ps; \
+            } \
+            if (p.out0.p) \
+                store4(p.out0, p.out0_f32, (long)n * p.out0.sN + (long)d * p.out0.sD + (long)h * p.out0.sH + (long)w * p.out0.sW + cb, v); \
+            if (p.out1.p) { \
+                float u[4]; \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) { \
+                    const float a = p.s2 ? v[r] * p.s2[cb + r] + p.t2[cb + r] : v[r]; \
+                    u[r] = apply_act(a, p.act1, p.slope1); \
+                } \
+                store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u); \
+            } \
+        } \
+    } \
+

@@ -178,6 +178,7 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 struct ConvCall {
     ConvParams p;
     int cfg = -1, mode = MODE_STD;
+    int hcfg = -1;            // forced conv_halo configuration (else derived from Cout_pad)
     double macs_per_pos = 0;
     const char* name = "";
 };
@@ -220,14 +221,40 @@ int pick_cfg(int Cout_pad)
     return CFG_256x16;
 }
 
+bool halo_enabled()
+{
+    static const bool on = getenv("CANONSWAP_NO_HALO") == nullptr;
+    return on;
+}
+
+int pick_halo_cfg(int Cout_pad, int mode)
+{
+    if (mode == MODE_PIXSHUF) return CFG_H_256x16;
+    if (Cout_pad % 128 == 0) return CFG_H_128x128;
+    if (Cout_pad % 64 == 0) return CFG_H_128x64;
+    if (Cout_pad % 32 == 0) return CFG_H_128x32;
+    return CFG_H_128x16;
+}
+
+// Launch one convolution. Default path: conv_halo (LDS-staged input patch, register-streamed weights);
+// conv_igemm handles the depth-collapsing occlusion conv (and everything when CANONSWAP_NO_HALO is set).
 int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
 {
+    const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
+    e->flops += fl;
+    if (halo_enabled() && c.p.inD == c.p.D) {
+        const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p.Cout_pad, c.mode);
+        const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16) ? 256 : 128;
+        const bool is3d = c.p.KD > 1;
+        if (!prefW) { prefW = is3d ? 8 : 16; prefH = is3d ? 8 : BM / 16; }
+        set_tile(c.p, BM, prefW, prefH);
+        const int ck = (!is3d && c.p.Cin % 64 == 0) ? 64 : 32;
+        return e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl);
+    }
     if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
     if (!prefW) { prefW = 16; prefH = BM / 16; }
     set_tile(c.p, BM, prefW, prefH);
-    const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
-    e->flops += fl;
     return e->run(0, st, [&] { return launch_conv(c.p, c.cfg, c.mode, st); }, c.name, fl);
 }
 
@@ -255,6 +282,7 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
         ConvCall c1 = mk(rb[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);   // conv1 with norm2 folded, ReLU
         c1.p.act0 = ACT_RELU;
         c1.p.out0 = hwdc3(e->va[1]);
+        c1.hcfg = CFG_H_256x32;
         TRY(go(e, c1, st, 4, 4));
         const int nxt = (*cur + 1) % 3;
         ConvCall c2 = mk(rb[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);   // conv2 + x
@@ -263,6 +291,7 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
         c2.p.out1 = hwdc3(e->va[0]);
         if (i < 5) { c2.p.s2 = rb[i].post.s; c2.p.t2 = rb[i].post.t; c2.p.act1 = ACT_RELU; }
         else if (final_post) { c2.p.s2 = final_post->s; c2.p.t2 = final_post->t; c2.p.act1 = final_act; }
+        c2.hcfg = CFG_H_256x32;
         TRY(go(e, c2, st, 4, 4));
         *cur = nxt;
     }
@@ -391,6 +420,7 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
         ConvCall c1 = mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
+        c1.hcfg = CFG_H_256x32;
         TRY(go(e, c1, st, 4, 4));
         float* s1;
         TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s1, st));
@@ -398,6 +428,7 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
                                                        e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }, "norm_act"));
         ConvCall c2 = mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
+        c2.hcfg = CFG_H_256x32;
         TRY(go(e, c2, st, 4, 4));
         float* s2;
         TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s2, st));
@@ -908,6 +939,14 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     p.out1 = td(d->out1, d->out1_sN, d->out1_sD, d->out1_sH, d->out1_sW);
     p.stats = d->stats;
     c.mode = d->mode;
+    if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo
+        const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p.Cout_pad, c.mode);
+        const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16) ? 256 : 128;
+        const bool is3d = p.KD > 1;
+        set_tile(p, BM, d->tile_w ? d->tile_w : (is3d ? 8 : 16), d->tile_h ? d->tile_h : (is3d ? 8 : BM / 16));
+        const int ck = d->ck ? d->ck : ((!is3d && p.Cin % 64 == 0) ? 64 : 32);
+        return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);
+    }
     c.cfg = d->cfg >= 0 ? d->cfg : pick_cfg(p.Cout_pad);
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
     set_tile(p, BM, d->tile_w ? d->tile_w : 16, d->tile_h ? d->tile_h : BM / 16);

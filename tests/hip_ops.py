@@ -21,7 +21,7 @@ def strides_cl(t):
 
 def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0="none", slope0=0.0, res=None, res_shift=0,
          pixscale=None, ps_stride=1, out0=None, s2=None, t2=None, act1="none", slope1=0.0, out1=None, stats=None,
-         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None):
+         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0):
     """x: [N, D, H, W, C] fp16 view (C contiguous). out0/out1/res: 5-D channels-last views. k = (KD, KH, KW)."""
     lib = _lib.load()
     d = _lib.ConvDesc()
@@ -55,6 +55,7 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
     d.stats = 0 if stats is None else stats.data_ptr()
     d.mode, d.cfg = mode, cfg
     d.tile_w, d.tile_h = tile
+    d.ck = ck
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.cs_op_conv(C.byref(d), st), "cs_op_conv")
 

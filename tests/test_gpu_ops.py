@@ -48,8 +48,16 @@ CASES = [
 ]
 
 
+KERNELS = ["igemm", "halo"]
+
+
+def _cfg(kern, igemm_cfg=-1, halo_cfg=-2):
+    return igemm_cfg if kern == "igemm" else halo_cfg
+
+
+@pytest.mark.parametrize("kern", KERNELS)
 @pytest.mark.parametrize("name,N,Cin,Cout,D,H,W,k,cfg", CASES)
-def test_conv_std(name, N, Cin, Cout, D, H, W, k, cfg):
+def test_conv_std(name, N, Cin, Cout, D, H, W, k, cfg, kern):
     import hip_ops as ops
     r = _rng(zlib.crc32(name.encode()) % 1000)
     x = _randn(r, N, Cin, D, H, W)
@@ -60,13 +68,14 @@ def test_conv_std(name, N, Cin, Cout, D, H, W, k, cfg):
     xd = _to_cl(x).to(DEV)
     wp = ops.packed_weight(w, cout_pad, DEV)
     out = torch.zeros(N, D, H, W, Cout, dtype=torch.float32, device=DEV)
-    ops.conv(xd, wp, cout_pad, Cout, k, bias=b.to(DEV), act0="relu", out0=out, cfg=cfg)
+    ops.conv(xd, wp, cout_pad, Cout, k, bias=b.to(DEV), act0="relu", out0=out, cfg=_cfg(kern))
     torch.cuda.synchronize()
     err = ops.rel_err(_from_cl(out), ref)
-    assert err < 2e-3, (name, err)
+    assert err < 2e-3, (name, kern, err)
 
 
-def test_conv_channel_slice_pad_and_upshift():
+@pytest.mark.parametrize("kern", KERNELS)
+def test_conv_channel_slice_pad_and_upshift(kern):
     """Cin = 112 read at channel offset 32 of a 144-wide buffer (dense-motion level 0) with nearest x2 up-sampling
     folded into addressing (UpBlock3d, util.py:142-147) and output into a wider concat buffer."""
     import hip_ops as ops
@@ -83,13 +92,14 @@ def test_conv_channel_slice_pad_and_upshift():
     wp = ops.packed_weight(w, 64, DEV)
     obuf = torch.full((N, D, 2 * Hs, 2 * Ws, 96), -5.0, dtype=torch.float16, device=DEV)
     ops.conv(buf[..., 32:], wp, 64, 64, (3, 3, 3), cin=112, bias=b.to(DEV), act0="relu", out0=obuf[..., :64], up_shift=1,
-             out_dims=(N, D, 2 * Hs, 2 * Ws))
+             out_dims=(N, D, 2 * Hs, 2 * Ws), cfg=_cfg(kern))
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(obuf[..., :64]), ref) < 3e-3
     assert bool((obuf[..., 64:] == -5.0).all())
 
 
-def test_conv_hwdc_residual_dual_output():
+@pytest.mark.parametrize("kern", KERNELS)
+def test_conv_hwdc_residual_dual_output(kern):
     """3x3x3 conv on the [H][W][D][C] feature-volume layout, fp32 residual stream, second pre-activated fp16 output
     (ResBlock3d, util.py:94-102)."""
     import hip_ops as ops
@@ -110,14 +120,15 @@ def test_conv_hwdc_residual_dual_output():
     out1 = torch.zeros(N, H, W, D, Cc, dtype=torch.float16, device=DEV)
     wp = ops.packed_weight(w, 32, DEV)
     ops.conv(view(xd), wp, 32, 32, (3, 3, 3), bias=b.to(DEV), res=view(resd), out0=view(out0), s2=s2.to(DEV), t2=t2.to(DEV),
-             act1="relu", out1=view(out1), tile=(4, 4))
+             act1="relu", out1=view(out1), tile=(4, 4), cfg=_cfg(kern, -1, 12))
     torch.cuda.synchronize()
     back = lambda t: t.float().cpu().permute(0, 4, 3, 1, 2)          # N H W D C -> N C D H W
     assert ops.rel_err(back(out0), y) < 2e-3
     assert ops.rel_err(back(out1), y2) < 3e-3
 
 
-def test_conv_tblend():
+@pytest.mark.parametrize("kern", KERNELS)
+def test_conv_tblend(kern):
     """Fused [W ; w_mod] conv + blend epilogue == AdaptiveSharedWeightConv2d (adaptive_modulate.py:139-186)."""
     import hip_ops as ops
     from canonswap_amd import pack
@@ -136,13 +147,14 @@ def test_conv_tblend():
     out = torch.zeros(N, 1, H, W, Cc, dtype=torch.float32, device=DEV)
     resd = res.permute(0, 2, 3, 1).contiguous().unsqueeze(1).to(DEV)
     ops.conv(_to_cl(x).to(DEV), wp, 2 * Cc, Cc, (1, 3, 3), bias=bias.to(DEV), pixscale=m4, ps_stride=4, res=resd, out0=out, mode=1,
-             cfg=0)
+             cfg=_cfg(kern, 0, 10))
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 2e-3
 
 
+@pytest.mark.parametrize("kern", KERNELS)
 @pytest.mark.parametrize("xshift", [0, 1])
-def test_conv_spade(xshift):
+def test_conv_spade(xshift, kern):
     """gamma/beta convs + instance-norm modulation epilogue == SPADE.forward (util.py:295-302) + leaky_relu(0.2)."""
     import hip_ops as ops
     from canonswap_amd import pack
@@ -164,12 +176,13 @@ def test_conv_spade(xshift):
     wp = torch.from_numpy(pack.pack_conv(pack.interleave16(wg.numpy(), wb.numpy()), 128)).to(DEV)
     out = torch.zeros(N, 1, S, S, Cc, dtype=torch.float16, device=DEV)
     ops.conv(_to_cl(actv).to(DEV), wp, 128, Cc, (1, 3, 3), bias=bg.to(DEV), bias2=bb.to(DEV), res=xd.unsqueeze(1), res_shift=xshift,
-             stats=stats, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=0)
+             stats=stats, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=_cfg(kern, 0, 10))
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
 
 
-def test_conv_pixel_shuffle_sigmoid():
+@pytest.mark.parametrize("kern", KERNELS)
+def test_conv_pixel_shuffle_sigmoid(kern):
     """conv 64->12 + PixelShuffle(2) + sigmoid (spade_generator.py:36-39,56-57)."""
     import hip_ops as ops
     r = _rng(16)
@@ -180,9 +193,32 @@ def test_conv_pixel_shuffle_sigmoid():
     wp = ops.packed_weight(w, 16, DEV)
     b16 = torch.zeros(16); b16[:12] = b
     out = torch.zeros(N, 3, 2 * S, 2 * S, dtype=torch.float32, device=DEV)
-    ops.conv(_to_cl(x).to(DEV), wp, 16, 16, (1, 3, 3), bias=b16.to(DEV), act0="sigmoid", out0=out, mode=3, cfg=3)
+    ops.conv(_to_cl(x).to(DEV), wp, 16, 16, (1, 3, 3), bias=b16.to(DEV), act0="sigmoid", out0=out, mode=3, cfg=_cfg(kern, 3, 15))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("name,N,Cin,Cout,D,H,W,k,ck", [
+    ("halo_2d_ck64_db", 2, 256, 128, 1, 32, 32, (1, 3, 3), 64),
+    ("halo_2d_ck32_db", 1, 160, 64, 1, 16, 32, (1, 3, 3), 32),
+    ("halo_2d_ck64_oddchunks", 1, 96, 128, 1, 16, 16, (1, 3, 3), 64),
+    ("halo_3d_multichunk", 1, 144, 64, 4, 16, 16, (3, 3, 3), 32),
+    ("halo_7x7x7_mask_like", 1, 144, 32, 4, 16, 16, (7, 7, 7), 32),
+    ("halo_1x1", 2, 256, 512, 1, 16, 16, (1, 1, 1), 64),
+    ("halo_n16", 1, 512, 16, 1, 16, 16, (1, 3, 3), 64),
+])
+def test_conv_halo_variants(name, N, Cin, Cout, D, H, W, k, ck):
+    import hip_ops as ops
+    r = _rng(zlib.crc32(name.encode()) % 1000)
+    x = _randn(r, N, Cin, D, H, W)
+    w = _randn(r, Cout, Cin, *k, scale=1.0 / np.sqrt(Cin * np.prod(k)))
+    b = _randn(r, Cout, scale=0.1)
+    ref = _ref_conv(x, w, b, tuple(kk // 2 for kk in k))
+    out = torch.zeros(N, D, H, W, Cout, dtype=torch.float32, device=DEV)
+    ops.conv(_to_cl(x).to(DEV), ops.packed_weight(w, Cout, DEV), Cout, Cout, k, bias=b.to(DEV), out0=out, cfg=-2, ck=ck)
+    torch.cuda.synchronize()
+    err = ops.rel_err(_from_cl(out), ref)
+    assert err < 2e-3, (name, err)
 
 
 def test_grid_sample_3d():
