@@ -35,13 +35,13 @@ __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, con
 }
 
 
-// Expects in scope: p, acc, n0, tw, th, td, tn, lgS, mW, mH, mD, wpx, wch, l15, l4 and the template constants
-// WPX, WCH, BM, MODE.
+// Expects in scope: p, ep_acc[WCH][EP_WPX] (f4_t), ep_wpx (position-block index of this wave), EP_WPX, n0, tw, th, td, tn,
+// lgS, mW, mH, mD, wch, l15, l4 and the template constants WCH, BM, MODE.
 #define CONV_EPILOGUE() \
     constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
 _Pragma("unroll") \
-    for (int pi = 0; pi < WPX; ++pi) { \
-        int m = wpx * WPX * 16 + pi * 16 + l15; \
+    for (int pi = 0; pi < EP_WPX; ++pi) { \
+        int m = ep_wpx * EP_WPX * 16 + pi * 16 + l15; \
         const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
         const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
         const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD; \
@@ -58,7 +58,7 @@ _Pragma("unroll") \
             if (MODE == MODE_TBLEND) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) \
-                    v[r] = ps * (acc[ci + CSTEP - 1][pi][r] + p.bias[cb + r]) + (1.f - ps) * acc[ci][pi][r]; \
+                    v[r] = ps * (ep_acc[ci + CSTEP - 1][pi][r] + p.bias[cb + r]) + (1.f - ps) * ep_acc[ci][pi][r]; \
             } else if (MODE == MODE_SPADE) { \
                 float x[4]; \
                 const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> p.res_shift) * p.res.sH + \
@@ -67,13 +67,13 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
                     const float* st = p.stats + ((long)n * p.Cout + cb + r) * 2; \
-                    const float g = acc[ci][pi][r] + p.bias[cb + r]; \
-                    const float b = acc[ci + CSTEP - 1][pi][r] + p.bias2[cb + r]; \
+                    const float g = ep_acc[ci][pi][r] + p.bias[cb + r]; \
+                    const float b = ep_acc[ci + CSTEP - 1][pi][r] + p.bias2[cb + r]; \
                     v[r] = (x[r] - st[0]) * st[1] * (1.f + g) + b; \
                 } \
             } else { \
 _Pragma("unroll") \
-                for (int r = 0; r < 4; ++r) v[r] = acc[ci][pi][r] + (p.bias ? p.bias[cb + r] : 0.f); \
+                for (int r = 0; r < 4; ++r) v[r] = ep_acc[ci][pi][r] + (p.bias ? p.bias[cb + r] : 0.f); \
             } \
 _Pragma("unroll") \
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act0, p.slope0); \

@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
         __syncthreads();
     }
 
+    constexpr int EP_WPX = WPX;
+    const int ep_wpx = wpx;
+    auto& ep_acc = acc;
     CONV_EPILOGUE()
 }
 

@@ -352,6 +352,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 32); m.p.out0_f32 = 1;
+    m.hcfg = CFG_H_SK128x32;
     TRY(go(e, m, st));
     TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, 32, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
     // occlusion (dense_motion.py:98-102): depth-collapsing (16 x 7 x 1)-tap conv, 7 horizontal taps as output channels
