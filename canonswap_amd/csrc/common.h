@@ -27,6 +27,7 @@ struct TDesc {
 struct ConvParams {
     // input activations, fp16, channels-last with arbitrary position strides
     const half_t* in;
+    const half_t* zero;  // >= 16 bytes of zeros: source of out-of-range / padded pieces (address select, no data select)
     long in_sN, in_sD, in_sH, in_sW;
     int N, D, H, W;     // output extents (the input is addressed at (h>>up_shift, w>>up_shift))
     int inD;            // input depth extent (== D except for the depth-collapsing occlusion conv)
@@ -75,6 +76,7 @@ void cs_set_error(const char* fmt, ...);
 // ---- kernel launchers (conv_igemm.hip, kernels.hip); all asynchronous on `st`
 int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st);
+const half_t* cs_zero_page();   // per-process device buffer of zeros (lazily allocated on the current device)
 
 int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);
 int launch_avgpool(const half_t* in, int N, int D, int H, int W, int C, TDesc out, hipStream_t st);

@@ -14,9 +14,24 @@
 //     positions, so each still issues 16 MFMAs per 8 LDS reads, and reduce their accumulators through LDS once.
 // Per K-step (32 channels of one tap) a wave issues WPX ds_read_b128 + WCH global_load_dwordx4 + WPX*WCH MFMAs.
 //
-// LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes, followed by a tap -> byte-offset table.
+// LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes.
 #include "common.h"
 #include "conv_epilogue.h"
+
+// Weight fragments are streamed with loads the compiler does not track (inline asm) and are waited for with an
+// explicit counted s_waitcnt: hipcc drains vmcnt to 0 at every loop back-edge for loads it tracks, which would
+// collapse the PFD-deep register ring to an effective depth of one K-step.
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void wfrag_load(u4_t& dst, const half_t* ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK>
 __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
@@ -24,8 +39,9 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP;
     constexpr int BN = WCH * 16 * WVC;
     constexpr int SL = CK / 8;           // 16-byte slots per voxel
-    constexpr int VS = CK * 2 + 16;      // LDS bytes per halo voxel
-    constexpr int HI = 6;                // halo pieces a thread holds in flight (double-buffered mode)
+    constexpr int SLP = SL + 1;          // ... plus one pad slot (bank spreading; also fetched, from the zero page)
+    constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
+    constexpr int HI = 8;                // halo pieces per thread whose source offsets are kept in registers
     constexpr int KH32 = CK / 32;        // 32-channel K-steps per tap and chunk
     constexpr int PFD = 4;               // weight prefetch depth in K-steps
     constexpr int SKS = SK ? 4 : 1;      // K-step stride of one wave
@@ -50,60 +66,64 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
     const int TN = BM >> lgS;
     const int HW = (1 << p.lgTW) + p.KW - 1, HH = (1 << p.lgTH) + p.KH - 1, HD = (1 << p.lgTD) + p.KD - 1;
     const int HV = TN * HD * HH * HW;
-    const int nitems = HV * SL;
+    const int nitems = HV * SLP;
     const int w0 = tw << p.lgTW, h0 = th << p.lgTH, d0 = td << p.lgTD, nb = tn * TN;
     const int ntaps = p.KD * p.KH * p.KW;
-    int* tofftab = (int*)(smem + (size_t)(DB ? 2 : 1) * HV * VS);     // tap -> LDS byte offset of the shifted window
-    for (int i = tid; i < ntaps; i += 256) {
-        const int kw = i % p.KW, r = i / p.KW;
-        tofftab[i] = (((r / p.KH) * HH + (r % p.KH)) * HW + kw) * VS;
-    }
 
-    // ---- halo staging: piece q = (voxel q / SL, 16-byte slot q % SL)
-    auto piece_src = [&](int q, int c0, bool& ok) -> const half_t* {
-        const int hv = q / SL, slot = q % SL;
+    // ---- halo staging, global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
+    // The LDS image is linear in the piece index q = voxel*SLP + slot (SLP = SL data slots + 1 pad slot), which is
+    // what the instruction requires (wave-uniform base + lane*16). Out-of-range / pad pieces read the zero page.
+    auto piece_off = [&](int q, bool& inb) -> long {      // element offset of piece q's voxel (without the channel part)
+        const int hv = q / SLP;
         const int hw = hv % HW; int r = hv / HW;
         const int hh = r % HH; r /= HH;
         const int hd = r % HD;
         const int hn = r / HD;
-        const int n = nb + hn, id = d0 + hd - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW, c = c0 + slot * 8;
-        ok = q < nitems && n < p.N && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W &&
-             c < p.Cin;
-        return p.in + (long)n * p.in_sN + (long)id * p.in_sD + (long)(ih >> p.up_shift) * p.in_sH +
-               (long)(iw >> p.up_shift) * p.in_sW + c;
+        const int n = nb + hn, id = d0 + hd - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW;
+        inb = q < nitems && (q % SLP) < SL && n < p.N && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H &&
+              (unsigned)iw < (unsigned)p.W;
+        return (long)n * p.in_sN + (long)id * p.in_sD + (long)(ih >> p.up_shift) * p.in_sH + (long)(iw >> p.up_shift) * p.in_sW +
+               (q % SLP) * 8;
     };
-    auto piece_dst = [&](int q, int buf) -> uint4* {
-        return (uint4*)(smem + (size_t)buf * HV * VS + (size_t)(q / SL) * VS + (q % SL) * 16);
-    };
-    auto fill_halo = [&](int buf, int c0) {      // synchronous fill, batches of 8 loads in flight per thread
-        for (int q0 = tid; q0 < nitems; q0 += 256 * 8) {
-            uint4 v[8];
+    // few pieces per thread: keep their offsets in registers (always the case in double-buffered mode, see launcher)
+    const bool pre = DB || nitems <= 256 * HI;
+    int poff[HI];
+    unsigned pmask = 0;
+    if (pre) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool ok;
-                const half_t* src = piece_src(q0 + 256 * j, c0, ok);
-                v[j] = make_uint4(0, 0, 0, 0);
-                if (ok) v[j] = *(const uint4*)src;
+        for (int j = 0; j < HI; ++j) {
+            bool inb;
+            const long o = piece_off(tid + 256 * j, inb);
+            poff[j] = inb ? (int)o : 0;
+            pmask |= inb ? (1u << j) : 0u;
+        }
+    }
+    auto glds = [&](const half_t* src, int buf, int q_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (size_t)buf * HV * VS + (size_t)q_wave_base * 16),
+                                         16, 0, 0);
+    };
+    auto stage_halo = [&](int buf, int c0) {     // asynchronous: completion is awaited by the next __syncthreads()
+        if (pre) {
+#pragma unroll
+            for (int j = 0; j < HI; ++j) {
+                const int q = tid + 256 * j;
+                if (q < nitems) {
+                    const bool ok = ((pmask >> j) & 1u) && (c0 + (q % SLP) * 8 < p.Cin);
+                    glds(ok ? p.in + poff[j] + c0 : p.zero, buf, 256 * j + wave * 64);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (q0 + 256 * j < nitems) *piece_dst(q0 + 256 * j, buf) = v[j];
+        } else if constexpr (!DB) {
+            for (int q0 = 0; q0 < nitems; q0 += 256) {
+                const int q = q0 + tid;
+                if (q < nitems) {
+                    bool inb;
+                    const long o = piece_off(q, inb);
+                    const bool ok = inb && (c0 + (q % SLP) * 8 < p.Cin);
+                    glds(ok ? p.in + o + c0 : p.zero, buf, q0 + wave * 64);
+                }
+            }
         }
-    };
-    uint4 hreg[DB ? HI : 1];
-    auto prefetch_issue = [&](int c0) {
-#pragma unroll
-        for (int j = 0; j < (DB ? HI : 1); ++j) {
-            bool ok;
-            const half_t* src = piece_src(tid + 256 * j, c0, ok);
-            hreg[j] = make_uint4(0, 0, 0, 0);
-            if (ok) hreg[j] = *(const uint4*)src;
-        }
-    };
-    auto prefetch_commit = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < (DB ? HI : 1); ++j)
-            if (tid + 256 * j < nitems) *piece_dst(tid + 256 * j, buf) = hreg[j];
     };
 
     // ---- per-lane constants of the MFMA operand fetches
@@ -122,26 +142,40 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
     const int nck = (p.Cin + CK - 1) / CK;
     const int j0 = SK ? wave : 0;
 
-    // This wave's K-step sequence: for every chunk cc, local steps j = j0, j0+SKS, ... < ntaps*nhalf(cc), with
-    // tap = j / nhalf, half = j % nhalf, packed index kidx = (cc*KH32 + half)*ntaps + tap.
-    auto chunk_steps = [&](int cc) -> int {
+    // This wave's K-step sequence: for every chunk cc, "fine" steps j = j0, j0+SKS, ... < ntaps*nhalf(cc) with
+    // tap = j / nhalf, half = j % nhalf; packed weight index kidx = (cc*KH32 + half)*ntaps + tap. Two scalar iterators
+    // walk it: the producer (weight prefetch, PFD steps ahead) and the consumer.
+    auto chunk_nhalf = [&](int cc) -> int {
         const int rem = p.nchunks - cc * KH32;
-        return ntaps * (rem < KH32 ? rem : KH32);
+        return rem < KH32 ? rem : KH32;
     };
-    int pcc = 0, pj = j0, psteps = chunk_steps(0);        // producer (weight prefetch) position
-    auto wload = [&](h8_t (&dst)[WCH]) {
-        while (pcc < nck && pj >= psteps) { ++pcc; pj = j0; psteps = pcc < nck ? chunk_steps(pcc) : 0; }
-        if (pcc < nck) {
-            const bool two = psteps == 2 * ntaps;
-            const int tap = two ? pj >> 1 : pj, half = two ? pj & 1 : 0;
-            const long off = (long)((pcc * KH32 + half) * ntaps + tap) * wstep;
-#pragma unroll
-            for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const h8_t*)(wlane + off + ci * 512);
-            pj += SKS;
-        } else {
-#pragma unroll
-            for (int ci = 0; ci < WCH; ++ci) dst[ci] = (h8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        }
+    struct It { int cc, nh, tap, half; };
+    auto it_init = [&](It& it) {
+        it.cc = 0; it.nh = chunk_nhalf(0); it.tap = 0; it.half = j0;
+        while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+    };
+    auto it_chunk_done = [&](const It& it) -> bool { return it.tap >= ntaps; };
+    auto it_next_chunk = [&](It& it) {
+        ++it.cc; it.nh = it.cc < nck ? chunk_nhalf(it.cc) : 1; it.tap = 0; it.half = j0;
+        while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+    };
+    auto it_advance = [&](It& it) {
+        it.half += SKS;
+        while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+    };
+    It P;                                // producer
+    it_init(P);
+    long last_off = 0;
+    auto wload = [&](u4_t (&dst)[WCH]) {
+        while (P.cc < nck && it_chunk_done(P)) it_next_chunk(P);
+        if (P.cc < nck) { last_off = (long)((P.cc * KH32 + P.half) * ntaps + P.tap) * wstep; it_advance(P); }
+        // past the end the last valid fragment is re-read (never consumed): every step issues exactly WCH loads, so the
+        // counted wait below is exact in steady state and conservative otherwise
+        const half_t* src = wlane + last_off;
+        wfrag_load<0>(dst[0], src);
+        if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
+        if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
+        if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
     };
 
     f4_t acc[WCH][WPX];
@@ -150,48 +184,54 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
 #pragma unroll
         for (int pi = 0; pi < WPX; ++pi) acc[ci][pi] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
-    h8_t wr[PFD][WCH];
+    u4_t wr[PFD][WCH];
 #pragma unroll
     for (int i = 0; i < PFD; ++i) wload(wr[i]);
 
-    fill_halo(0, 0);
+    stage_halo(0, 0);
     __syncthreads();
-    if (DB && nck > 1) prefetch_issue(CK);
-    int cur = 0, cc = 0, cj = j0, csteps = chunk_steps(0);
+    if (DB && nck > 1) stage_halo(1, CK);
+    int cur = 0;
+    It C;                                // consumer
+    it_init(C);
+    // (kd, kh, kw) of C.tap, kept incrementally
+    int ckw = C.tap % p.KW, ckh = (C.tap / p.KW) % p.KH, ckd = C.tap / (p.KW * p.KH), ctap = C.tap;
     const unsigned char* hb = smem;
     bool done = false;
     while (!done) {
 #pragma unroll
         for (int i = 0; i < PFD; ++i) {
-            while (!done && cj >= csteps) {                // this wave finished its share of chunk cc
-                if (cc + 1 >= nck) { done = true; break; }
+            while (!done && it_chunk_done(C)) {            // this wave finished its share of chunk C.cc
+                if (C.cc + 1 >= nck) { done = true; break; }
                 if (DB) {
-                    prefetch_commit(cur ^ 1);              // buffer cur^1 was last read in chunk cc-1 (behind the previous barrier)
-                    __syncthreads();
+                    __syncthreads();                       // chunk cc+1 has landed in buffer cur^1; everyone left buffer cur
+                    if (C.cc + 2 < nck) stage_halo(cur, (C.cc + 2) * CK);
                     cur ^= 1;
-                    if (cc + 2 < nck) prefetch_issue((cc + 2) * CK);
                 } else {
                     __syncthreads();                       // everyone is done reading the single buffer
-                    fill_halo(0, (cc + 1) * CK);
+                    stage_halo(0, (C.cc + 1) * CK);
                     __syncthreads();
                 }
-                ++cc; cj = j0; csteps = chunk_steps(cc);
+                it_next_chunk(C);
+                ctap = C.tap; ckw = ctap % p.KW; ckh = (ctap / p.KW) % p.KH; ckd = ctap / (p.KW * p.KH);
                 hb = smem + (size_t)cur * HV * VS;
             }
             if (done) break;
-            const bool two = csteps == 2 * ntaps;
-            const int tap = two ? cj >> 1 : cj, half = two ? cj & 1 : 0;
-            const int toff = tofftab[tap] + half * 64;
+            while (ctap < C.tap) { ++ctap; if (++ckw == p.KW) { ckw = 0; if (++ckh == p.KH) { ckh = 0; ++ckd; } } }
+            const int toff = ((ckd * HH + ckh) * HW + ckw) * VS + C.half * 64;
             h8_t af[WPX];
 #pragma unroll
             for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
+            wait_vmcnt_le<WCH*(PFD - 1)>();               // the WCH loads of this step's slot are older than the last WCH*(PFD-1)
+            __builtin_amdgcn_sched_barrier(0);             // keep the MFMAs below the wait (hipcc would hoist them)
 #pragma unroll
             for (int ci = 0; ci < WCH; ++ci)
 #pragma unroll
                 for (int pi = 0; pi < WPX; ++pi)
-                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[i][ci], af[pi], acc[ci][pi], 0, 0, 0);
+                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[i][ci]), af[pi], acc[ci][pi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);             // ... and the reload of the slot below its last reader
             wload(wr[i]);
-            cj += SKS;
+            it_advance(C);
         }
     }
 
@@ -235,7 +275,7 @@ template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK>
 static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
 {
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP, BN = WCH * 16 * WVC;
-    constexpr int VS = CK * 2 + 16, SL = CK / 8;
+    constexpr int SLP = CK / 8 + 1, VS = SLP * 16;
     if (p.Cout_pad % BN != 0) { cs_set_error("conv_halo: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
     if (p.inD != p.D) { cs_set_error("conv_halo: depth-collapsing convs are not supported"); return -1; }
     const int lgS = p.lgTW + p.lgTH + p.lgTD;
@@ -243,8 +283,8 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
     const int TN = BM >> lgS;
     const long HV = (long)TN * ((1 << p.lgTD) + p.KD - 1) * ((1 << p.lgTH) + p.KH - 1) * ((1 << p.lgTW) + p.KW - 1);
     const int nck = (p.Cin + CK - 1) / CK;
-    const bool db = nck > 1 && HV * SL <= 256 * 6 && 2 * HV * VS <= 64 * 1024;
-    size_t lds = (size_t)(db ? 2 : 1) * HV * VS + (size_t)p.KD * p.KH * p.KW * sizeof(int);
+    const bool db = nck > 1 && 2 * HV * VS <= 64 * 1024 && HV * SLP <= 256 * 8;
+    size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));

@@ -189,6 +189,7 @@ ConvCall mk(const ConvL& L, const void* in, TDesc ind, int N, int D, int H, int 
     memset(&c.p, 0, sizeof(c.p));
     ConvParams& p = c.p;
     p.in = (const half_t*)in;
+    p.zero = cs_zero_page();
     p.in_sN = ind.sN; p.in_sD = ind.sD; p.in_sH = ind.sH; p.in_sW = ind.sW;
     p.N = N; p.D = D; p.H = H; p.W = W; p.inD = D;
     p.Cin = L.Cin; p.nchunks = (L.Cin + 31) / 32; p.up_shift = up_shift;
@@ -928,7 +929,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     ConvCall c;
     memset(&c.p, 0, sizeof(c.p));
     ConvParams& p = c.p;
-    p.in = (const half_t*)d->in; p.in_sN = d->in_sN; p.in_sD = d->in_sD; p.in_sH = d->in_sH; p.in_sW = d->in_sW;
+    p.in = (const half_t*)d->in; p.zero = cs_zero_page(); p.in_sN = d->in_sN; p.in_sD = d->in_sD; p.in_sH = d->in_sH; p.in_sW = d->in_sW;
     p.N = d->N; p.D = d->D; p.H = d->H; p.W = d->W; p.inD = d->D; p.Cin = d->Cin; p.nchunks = (d->Cin + 31) / 32; p.up_shift = d->up_shift;
     p.KD = d->KD; p.KH = d->KH; p.KW = d->KW; p.PD = d->KD / 2; p.PH = d->KH / 2; p.PW = d->KW / 2;
     p.wgt = (const half_t*)d->wgt; p.Cout_pad = d->Cout_pad; p.Cout = d->Cout;

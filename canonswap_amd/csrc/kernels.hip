@@ -13,6 +13,18 @@
         if (_e != hipSuccess) { cs_set_error(name ": %s", hipGetErrorString(_e)); return -1; } \
     } while (0)
 
+const half_t* cs_zero_page()
+{
+    static void* zp[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!zp[dev]) {
+        if (hipMalloc(&zp[dev], 256) != hipSuccess) return nullptr;
+        (void)hipMemset(zp[dev], 0, 256);
+    }
+    return (const half_t*)zp[dev];
+}
+
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------------
