@@ -235,6 +235,11 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
         }
     }
 
+    // The ring still has untracked loads in flight (re-reads issued by the last PFD steps): drain them before the
+    // compiler reuses those VGPRs in the epilogue.
+    wait_vmcnt_le<0>();
+    __builtin_amdgcn_sched_barrier(0);
+
     if constexpr (!SK) {
         constexpr int EP_WPX = WPX;
         const int ep_wpx = wpx;

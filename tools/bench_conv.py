@@ -53,7 +53,10 @@ def run(name, N, Cin, Cout, D, H, W, k, us, hcfg, tile, kern):
 
 
 def main():
+    only = os.environ.get("BENCH_ONLY")
     for s in SHAPES:
+        if only and only not in s[0]:
+            continue
         res = []
         for kern in ("igemm", "halo"):
             try:
