@@ -14,7 +14,7 @@ enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3 };
 enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
 // tile configurations of conv_halo
 enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 13, CFG_H_128x16 = 14, CFG_H_256x16 = 15,
-       CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */ };
+       CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */, CFG_H_128x256 = 17 };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {

@@ -33,9 +33,19 @@ __device__ __forceinline__ void wait_vmcnt_le()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK>
-__global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
+// Static shapes (ST): the kernel extent and the position tile are compile-time constants, so the tap loop of a chunk is
+// fully unrolled: LDS window offsets become instruction immediates and all iterator arithmetic disappears.
+//   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
+template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
+template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
+template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 4; };
+
+template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
+__global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(const ConvParams p)
 {
+    using SS = StaticShape<ST>;
+    static_assert(ST == 0 || !SK, "static shapes are not combined with split-K");
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP;
     constexpr int BN = WCH * 16 * WVC;
     constexpr int SL = CK / 8;           // 16-byte slots per voxel
@@ -61,14 +71,16 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
     const int td = t % p.nTD; t /= p.nTD;
     const int tn = t;
     const int n0 = blockIdx.y * BN;
-    const int lgS = p.lgTW + p.lgTH + p.lgTD;
-    const int mW = (1 << p.lgTW) - 1, mH = (1 << p.lgTH) - 1, mD = (1 << p.lgTD) - 1;
+    const int lgTW = ST ? SS::LW : p.lgTW, lgTH = ST ? SS::LH : p.lgTH, lgTD = ST ? SS::LD : p.lgTD;
+    const int KD = ST ? SS::KD : p.KD, KH = ST ? SS::KH : p.KH, KW = ST ? SS::KW : p.KW;
+    const int lgS = lgTW + lgTH + lgTD;
+    const int mW = (1 << lgTW) - 1, mH = (1 << lgTH) - 1, mD = (1 << lgTD) - 1;
     const int TN = BM >> lgS;
-    const int HW = (1 << p.lgTW) + p.KW - 1, HH = (1 << p.lgTH) + p.KH - 1, HD = (1 << p.lgTD) + p.KD - 1;
+    const int HW = (1 << lgTW) + KW - 1, HH = (1 << lgTH) + KH - 1, HD = (1 << lgTD) + KD - 1;
     const int HV = TN * HD * HH * HW;
     const int nitems = HV * SLP;
-    const int w0 = tw << p.lgTW, h0 = th << p.lgTH, d0 = td << p.lgTD, nb = tn * TN;
-    const int ntaps = p.KD * p.KH * p.KW;
+    const int w0 = tw << lgTW, h0 = th << lgTH, d0 = td << lgTD, nb = tn * TN;
+    const int ntaps = KD * KH * KW;
 
     // ---- halo staging, global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
     // The LDS image is linear in the piece index q = voxel*SLP + slot (SLP = SL data slots + 1 pad slot), which is
@@ -131,9 +143,9 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
 #pragma unroll
     for (int pi = 0; pi < WPX; ++pi) {
         int m = wpx * WPX * 16 + pi * 16 + l15;
-        const int wl = m & mW; m >>= p.lgTW;
-        const int hl = m & mH; m >>= p.lgTH;
-        const int dl = m & mD; m >>= p.lgTD;
+        const int wl = m & mW; m >>= lgTW;
+        const int hl = m & mH; m >>= lgTH;
+        const int dl = m & mD; m >>= lgTD;
         abase[pi] = (((m * HD + dl) * HH + hl) * HW + wl) * VS + l4 * 16;
     }
     // weights: fragment ci of K-step kidx = 1 KiB at wgt + (kidx*Cout_pad + n0 + wch*WCH*16 + ci*16)*32; lane = (row l15, k l4*8)
@@ -142,96 +154,148 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
     const int nck = (p.Cin + CK - 1) / CK;
     const int j0 = SK ? wave : 0;
 
-    // This wave's K-step sequence: for every chunk cc, "fine" steps j = j0, j0+SKS, ... < ntaps*nhalf(cc) with
-    // tap = j / nhalf, half = j % nhalf; packed weight index kidx = (cc*KH32 + half)*ntaps + tap. Two scalar iterators
-    // walk it: the producer (weight prefetch, PFD steps ahead) and the consumer.
-    auto chunk_nhalf = [&](int cc) -> int {
-        const int rem = p.nchunks - cc * KH32;
-        return rem < KH32 ? rem : KH32;
-    };
-    struct It { int cc, nh, tap, half; };
-    auto it_init = [&](It& it) {
-        it.cc = 0; it.nh = chunk_nhalf(0); it.tap = 0; it.half = j0;
-        while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
-    };
-    auto it_chunk_done = [&](const It& it) -> bool { return it.tap >= ntaps; };
-    auto it_next_chunk = [&](It& it) {
-        ++it.cc; it.nh = it.cc < nck ? chunk_nhalf(it.cc) : 1; it.tap = 0; it.half = j0;
-        while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
-    };
-    auto it_advance = [&](It& it) {
-        it.half += SKS;
-        while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
-    };
-    It P;                                // producer
-    it_init(P);
-    long last_off = 0;
-    auto wload = [&](u4_t (&dst)[WCH]) {
-        while (P.cc < nck && it_chunk_done(P)) it_next_chunk(P);
-        if (P.cc < nck) { last_off = (long)((P.cc * KH32 + P.half) * ntaps + P.tap) * wstep; it_advance(P); }
-        // past the end the last valid fragment is re-read (never consumed): every step issues exactly WCH loads, so the
-        // counted wait below is exact in steady state and conservative otherwise
-        const half_t* src = wlane + last_off;
-        wfrag_load<0>(dst[0], src);
-        if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
-        if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
-        if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
-    };
-
     f4_t acc[WCH][WPX];
 #pragma unroll
     for (int ci = 0; ci < WCH; ++ci)
 #pragma unroll
         for (int pi = 0; pi < WPX; ++pi) acc[ci][pi] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
-    u4_t wr[PFD][WCH];
+    if constexpr (ST != 0) {
+        // ---------------- static shape: the K-steps of a chunk are fully unrolled
+        constexpr int NT = SS::KD * SS::KH * SS::KW, NS = NT * KH32;
+        constexpr int PFS = NS % 3 == 0 ? 3 : (NS % 2 == 0 ? 2 : 1);      // ring depth dividing the chunk length
+        constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
+        u4_t wr[PFS][WCH];
+        auto wload_at = [&](u4_t (&dst)[WCH], int cc, int st) {          // st: compile-time after unrolling
+            const int ccl = cc < nck ? cc : nck - 1;                      // past the end: harmless re-read
+            const half_t* src = wlane + (long)((ccl * KH32 + st % KH32) * NT + st / KH32) * wstep;
+            wfrag_load<0>(dst[0], src);
+            if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
+            if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
+            if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
+        };
 #pragma unroll
-    for (int i = 0; i < PFD; ++i) wload(wr[i]);
-
-    stage_halo(0, 0);
-    __syncthreads();
-    if (DB && nck > 1) stage_halo(1, CK);
-    int cur = 0;
-    It C;                                // consumer
-    it_init(C);
-    // (kd, kh, kw) of C.tap, kept incrementally
-    int ckw = C.tap % p.KW, ckh = (C.tap / p.KW) % p.KH, ckd = C.tap / (p.KW * p.KH), ctap = C.tap;
-    const unsigned char* hb = smem;
-    bool done = false;
-    while (!done) {
-#pragma unroll
-        for (int i = 0; i < PFD; ++i) {
-            while (!done && it_chunk_done(C)) {            // this wave finished its share of chunk C.cc
-                if (C.cc + 1 >= nck) { done = true; break; }
+        for (int st = 0; st < PFS; ++st) wload_at(wr[st], st / NS, st % NS);
+        stage_halo(0, 0);
+        __syncthreads();
+        if (DB && nck > 1) stage_halo(1, CK);
+        for (int cc = 0; cc < nck; ++cc) {
+            if (cc > 0) {
                 if (DB) {
-                    __syncthreads();                       // chunk cc+1 has landed in buffer cur^1; everyone left buffer cur
-                    if (C.cc + 2 < nck) stage_halo(cur, (C.cc + 2) * CK);
-                    cur ^= 1;
+                    __syncthreads();                       // chunk cc has landed in buffer cc&1; everyone left the other one
+                    if (cc + 1 < nck) stage_halo((cc + 1) & 1, (cc + 1) * CK);
                 } else {
-                    __syncthreads();                       // everyone is done reading the single buffer
-                    stage_halo(0, (C.cc + 1) * CK);
+                    __syncthreads();
+                    stage_halo(0, cc * CK);
                     __syncthreads();
                 }
-                it_next_chunk(C);
-                ctap = C.tap; ckw = ctap % p.KW; ckh = (ctap / p.KW) % p.KH; ckd = ctap / (p.KW * p.KH);
-                hb = smem + (size_t)cur * HV * VS;
             }
-            if (done) break;
-            while (ctap < C.tap) { ++ctap; if (++ckw == p.KW) { ckw = 0; if (++ckh == p.KH) { ckh = 0; ++ckd; } } }
-            const int toff = ((ckd * HH + ckh) * HW + ckw) * VS + C.half * 64;
-            h8_t af[WPX];
+            const unsigned char* hb = smem + (size_t)(DB ? (cc & 1) : 0) * HV * VS;
 #pragma unroll
-            for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
-            wait_vmcnt_le<WCH*(PFD - 1)>();               // the WCH loads of this step's slot are older than the last WCH*(PFD-1)
-            __builtin_amdgcn_sched_barrier(0);             // keep the MFMAs below the wait (hipcc would hoist them)
+            for (int st = 0; st < NS; ++st) {
+                const int tap = st / KH32, half = st % KH32;
+                const int toff = (((tap / (SS::KW * SS::KH)) * SHH + (tap / SS::KW) % SS::KH) * SHW + tap % SS::KW) * VS + half * 64;
+                h8_t af[WPX];
 #pragma unroll
-            for (int ci = 0; ci < WCH; ++ci)
+                for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
+                wait_vmcnt_le<WCH*(PFS - 1)>();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pi = 0; pi < WPX; ++pi)
-                    acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[i][ci]), af[pi], acc[ci][pi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);             // ... and the reload of the slot below its last reader
-            wload(wr[i]);
-            it_advance(C);
+                for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+                    for (int pi = 0; pi < WPX; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), af[pi],
+                                                                             acc[ci][pi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wload_at(wr[st % PFS], cc + (st + PFS) / NS, (st + PFS) % NS);
+            }
+        }
+    } else {
+        // This wave's K-step sequence: for every chunk cc, "fine" steps j = j0, j0+SKS, ... < ntaps*nhalf(cc) with
+        // tap = j / nhalf, half = j % nhalf; packed weight index kidx = (cc*KH32 + half)*ntaps + tap. Two scalar iterators
+        // walk it: the producer (weight prefetch, PFD steps ahead) and the consumer.
+        auto chunk_nhalf = [&](int cc) -> int {
+            const int rem = p.nchunks - cc * KH32;
+            return rem < KH32 ? rem : KH32;
+        };
+        struct It { int cc, nh, tap, half; };
+        auto it_init = [&](It& it) {
+            it.cc = 0; it.nh = chunk_nhalf(0); it.tap = 0; it.half = j0;
+            while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+        };
+        auto it_chunk_done = [&](const It& it) -> bool { return it.tap >= ntaps; };
+        auto it_next_chunk = [&](It& it) {
+            ++it.cc; it.nh = it.cc < nck ? chunk_nhalf(it.cc) : 1; it.tap = 0; it.half = j0;
+            while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+        };
+        auto it_advance = [&](It& it) {
+            it.half += SKS;
+            while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+        };
+        It P;                                // producer
+        it_init(P);
+        long last_off = 0;
+        auto wload = [&](u4_t (&dst)[WCH]) {
+            while (P.cc < nck && it_chunk_done(P)) it_next_chunk(P);
+            if (P.cc < nck) { last_off = (long)((P.cc * KH32 + P.half) * ntaps + P.tap) * wstep; it_advance(P); }
+            // past the end the last valid fragment is re-read (never consumed): every step issues exactly WCH loads, so the
+            // counted wait below is exact in steady state and conservative otherwise
+            const half_t* src = wlane + last_off;
+            wfrag_load<0>(dst[0], src);
+            if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
+            if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
+            if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
+        };
+
+        u4_t wr[PFD][WCH];
+    #pragma unroll
+        for (int i = 0; i < PFD; ++i) wload(wr[i]);
+
+        stage_halo(0, 0);
+        __syncthreads();
+        if (DB && nck > 1) stage_halo(1, CK);
+        int cur = 0;
+        It C;                                // consumer
+        it_init(C);
+        // (kd, kh, kw) of C.tap, kept incrementally
+        int ckw = C.tap % KW, ckh = (C.tap / KW) % KH, ckd = C.tap / (KW * KH), ctap = C.tap;
+        const unsigned char* hb = smem;
+        bool done = false;
+        while (!done) {
+    #pragma unroll
+            for (int i = 0; i < PFD; ++i) {
+                while (!done && it_chunk_done(C)) {            // this wave finished its share of chunk C.cc
+                    if (C.cc + 1 >= nck) { done = true; break; }
+                    if (DB) {
+                        __syncthreads();                       // chunk cc+1 has landed in buffer cur^1; everyone left buffer cur
+                        if (C.cc + 2 < nck) stage_halo(cur, (C.cc + 2) * CK);
+                        cur ^= 1;
+                    } else {
+                        __syncthreads();                       // everyone is done reading the single buffer
+                        stage_halo(0, (C.cc + 1) * CK);
+                        __syncthreads();
+                    }
+                    it_next_chunk(C);
+                    ctap = C.tap; ckw = ctap % KW; ckh = (ctap / KW) % KH; ckd = ctap / (KW * KH);
+                    hb = smem + (size_t)cur * HV * VS;
+                }
+                if (done) break;
+                while (ctap < C.tap) { ++ctap; if (++ckw == KW) { ckw = 0; if (++ckh == KH) { ckh = 0; ++ckd; } } }
+                const int toff = ((ckd * HH + ckh) * HW + ckw) * VS + C.half * 64;
+                h8_t af[WPX];
+    #pragma unroll
+                for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
+                wait_vmcnt_le<WCH*(PFD - 1)>();               // the WCH loads of this step's slot are older than the last WCH*(PFD-1)
+                __builtin_amdgcn_sched_barrier(0);             // keep the MFMAs below the wait (hipcc would hoist them)
+    #pragma unroll
+                for (int ci = 0; ci < WCH; ++ci)
+    #pragma unroll
+                    for (int pi = 0; pi < WPX; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[i][ci]), af[pi], acc[ci][pi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);             // ... and the reload of the slot below its last reader
+                wload(wr[i]);
+                it_advance(C);
+            }
         }
     }
 
@@ -276,8 +340,8 @@ __global__ void __launch_bounds__(256) conv_halo_kernel(const ConvParams p)
     }
 }
 
-template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK>
-static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
+template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK, int ST>
+static int launch_halo_st(const ConvParams& p, hipStream_t st)
 {
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP, BN = WCH * 16 * WVC;
     constexpr int SLP = CK / 8 + 1, VS = SLP * 16;
@@ -295,11 +359,11 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
     hipError_t e;
     if (db) {
-        auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, true, SK>;
+        auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, true, SK, ST>;
         if (lds > 64 * 1024) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)e; }
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
     } else {
-        auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, false, SK>;
+        auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, false, SK, ST>;
         if (lds > 64 * 1024) { e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)e; }
         hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
     }
@@ -308,23 +372,41 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
     return 0;
 }
 
+// picks the static-shape instantiation STV when the launch matches it, else the dynamic kernel
+template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK, int STV>
+static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
+{
+    if constexpr (STV != 0) {
+        using SS = StaticShape<STV>;
+        if (p.KD == SS::KD && p.KH == SS::KH && p.KW == SS::KW && p.lgTW == SS::LW && p.lgTH == SS::LH && p.lgTD == SS::LD &&
+            p.Cin % CK == 0)
+            return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, STV>(p, st);
+    }
+    return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, 0>(p, st);
+}
+
 // cfg: CFG_H_* (common.h); ck: 32 or 64
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st)
 {
-#define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK)                                          \
-    if (cfg == CFG && mode == MODE) {                                                         \
-        if (ck == 64) return launch_halo_cfg<64, WPX, WCH, WVP, WVC, MODE, SK>(p, st);       \
-        return launch_halo_cfg<32, WPX, WCH, WVP, WVC, MODE, SK>(p, st);                      \
+    const int stv = p.KD == 1 ? 1 : (p.lgTD == 4 ? 3 : 2);      // candidate static shape for this launch
+#define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
+    if (cfg == CFG && mode == MODE) {                                                                    \
+        if (ck == 64) return launch_halo_cfg<64, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \
+        if (stv == 1) return launch_halo_cfg<32, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \
+        return launch_halo_cfg<32, WPX, WCH, WVP, WVC, MODE, SK, ST3D>(p, st);                           \
     }
-    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_STD, false)
-    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_TBLEND, false)
-    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_SPADE, false)
-    HALO_CASE(CFG_H_128x64, 4, 2, 2, 2, MODE_STD, false)
-    HALO_CASE(CFG_H_256x32, 4, 2, 4, 1, MODE_STD, false)
-    HALO_CASE(CFG_H_128x32, 2, 2, 4, 1, MODE_STD, false)
-    HALO_CASE(CFG_H_128x16, 2, 1, 4, 1, MODE_STD, false)
-    HALO_CASE(CFG_H_256x16, 4, 1, 4, 1, MODE_PIXSHUF, false)
-    HALO_CASE(CFG_H_SK128x32, 8, 2, 4, 1, MODE_STD, true)
+    HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_STD, false, 1, 0)
+    HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_TBLEND, false, 1, 0)
+    HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_SPADE, false, 1, 0)
+    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_STD, false, 1, 2)
+    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_TBLEND, false, 1, 0)
+    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_SPADE, false, 1, 0)
+    HALO_CASE(CFG_H_128x64, 4, 2, 2, 2, MODE_STD, false, 1, 2)
+    HALO_CASE(CFG_H_256x32, 4, 2, 4, 1, MODE_STD, false, 0, 3)
+    HALO_CASE(CFG_H_128x32, 2, 2, 4, 1, MODE_STD, false, 0, 2)
+    HALO_CASE(CFG_H_128x16, 2, 1, 4, 1, MODE_STD, false, 1, 0)
+    HALO_CASE(CFG_H_256x16, 4, 1, 4, 1, MODE_PIXSHUF, false, 0, 0)
+    HALO_CASE(CFG_H_SK128x32, 8, 2, 4, 1, MODE_STD, true, 0, 0)
 #undef HALO_CASE
     cs_set_error("conv_halo: unsupported cfg/mode %d/%d", cfg, mode);
     return -1;

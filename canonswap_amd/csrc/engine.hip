@@ -228,9 +228,12 @@ bool halo_enabled()
     return on;
 }
 
-int pick_halo_cfg(int Cout_pad, int mode)
+int pick_halo_cfg(const ConvParams& p, int mode)
 {
+    const int Cout_pad = p.Cout_pad;
     if (mode == MODE_PIXSHUF) return CFG_H_256x16;
+    // 128 positions x 256 channels (64 channels per wave) only exists as the fully unrolled 3x3 / 16x8-tile kernel
+    if (Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0) return CFG_H_128x256;
     if (Cout_pad % 128 == 0) return CFG_H_128x128;
     if (Cout_pad % 64 == 0) return CFG_H_128x64;
     if (Cout_pad % 32 == 0) return CFG_H_128x32;
@@ -244,7 +247,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
     e->flops += fl;
     if (halo_enabled() && c.p.inD == c.p.D) {
-        const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p.Cout_pad, c.mode);
+        const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16) ? 256 : 128;
         const bool is3d = c.p.KD > 1;
         if (!prefW) { prefW = is3d ? 8 : 16; prefH = is3d ? 8 : BM / 16; }
@@ -942,7 +945,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     p.stats = d->stats;
     c.mode = d->mode;
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo
-        const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p.Cout_pad, c.mode);
+        const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16) ? 256 : 128;
         const bool is3d = p.KD > 1;
         set_tile(p, BM, d->tile_w ? d->tile_w : (is3d ? 8 : 16), d->tile_h ? d->tile_h : (is3d ? 8 : BM / 16));

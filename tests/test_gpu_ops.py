@@ -206,6 +206,9 @@ def test_conv_pixel_shuffle_sigmoid(kern):
     ("halo_7x7x7_mask_like", 1, 144, 32, 4, 16, 16, (7, 7, 7), 32),
     ("halo_1x1", 2, 256, 512, 1, 16, 16, (1, 1, 1), 64),
     ("halo_n16", 1, 512, 16, 1, 16, 16, (1, 3, 3), 64),
+    ("halo_256wide_ck64", 2, 128, 256, 1, 32, 32, (1, 3, 3), 64),
+    ("halo_256wide_ck32", 1, 96, 512, 1, 16, 32, (1, 3, 3), 32),
+    ("halo_static3d_tail_like", 1, 160, 192, 4, 16, 16, (3, 3, 3), 32),
     ("halo_sk_7x7x7", 1, 144, 32, 4, 16, 16, (7, 7, 7), 32),
     ("halo_sk_3x3x3_multichunk", 2, 96, 32, 8, 8, 8, (3, 3, 3), 32),
     ("halo_sk_fewsteps", 1, 32, 32, 1, 16, 16, (1, 1, 1), 32),

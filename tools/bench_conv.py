@@ -15,6 +15,7 @@ DEV = "cuda:0"
 # name, N, Cin, Cout_pad, D, H, W, k, up_shift, halo cfg, tile, real_flop_factor
 SHAPES = [
     ("T fused 512->1024 3x3 @64 B8", 8, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("T fused 512->1024 3x3 (128x128)", 8, 512, 1024, 1, 64, 64, (1, 3, 3), 0, 10, (0, 0)),
     ("G conv 512->512 3x3 @64 B8", 8, 512, 512, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->1024 3x3 @64 B8", 8, 128, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->512 3x3 @256 B4", 4, 128, 512, 1, 256, 256, (1, 3, 3), 0, -2, (0, 0)),
