@@ -14,7 +14,8 @@ enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3 };
 enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
 // tile configurations of conv_halo
 enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 13, CFG_H_128x16 = 14, CFG_H_256x16 = 15,
-       CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */, CFG_H_128x256 = 17 };
+       CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */, CFG_H_128x256 = 17,
+       CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */ };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {
@@ -83,7 +84,7 @@ int launch_avgpool(const half_t* in, int N, int D, int H, int W, int C, TDesc ou
 int launch_dm_compress(const float* f, const float* w, const float* b, half_t* comp, int N, int D, int H, int W, hipStream_t st);
 int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, half_t* out, int out_stride, int N, int D,
                      int H, int W, hipStream_t st);
-int launch_dm_softmax(const float* logits, int lstride, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
+int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
                       int N, int D, int H, int W, hipStream_t st);
 int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
 int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);

@@ -36,10 +36,12 @@ __device__ __forceinline__ void wait_vmcnt_le()
 // Static shapes (ST): the kernel extent and the position tile are compile-time constants, so the tap loop of a chunk is
 // fully unrolled: LDS window offsets become instruction immediates and all iterator arithmetic disappears.
 //   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
+//   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 4; };
+template <> struct StaticShape<4> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 3, LH = 3, LD = 1; };
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(const ConvParams p)
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
     if constexpr (ST != 0) {
         // ---------------- static shape: the K-steps of a chunk are fully unrolled
         constexpr int NT = SS::KD * SS::KH * SS::KW, NS = NT * KH32;
-        constexpr int PFS = NS % 3 == 0 ? 3 : (NS % 2 == 0 ? 2 : 1);      // ring depth dividing the chunk length
+        constexpr int PFS = NS < 3 ? NS : 3;      // weight ring depth; the ring is re-primed at every chunk
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
         u4_t wr[PFS][WCH];
         auto wload_at = [&](u4_t (&dst)[WCH], int cc, int st) {          // st: compile-time after unrolling
@@ -173,13 +175,15 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
             if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
             if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
             if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
+            if constexpr (WCH > 4) wfrag_load<0>(dst[4], src + 2048);
         };
-#pragma unroll
-        for (int st = 0; st < PFS; ++st) wload_at(wr[st], st / NS, st % NS);
         stage_halo(0, 0);
         __syncthreads();
         if (DB && nck > 1) stage_halo(1, CK);
         for (int cc = 0; cc < nck; ++cc) {
+            // prime the ring with this chunk's first steps before waiting on the halo: both latencies overlap
+#pragma unroll
+            for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
             if (cc > 0) {
                 if (DB) {
                     __syncthreads();                       // chunk cc has landed in buffer cc&1; everyone left the other one
@@ -207,7 +211,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
                         acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), af[pi],
                                                                              acc[ci][pi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                wload_at(wr[st % PFS], cc + (st + PFS) / NS, (st + PFS) % NS);
+                wload_at(wr[st % PFS], cc, st + PFS < NS ? st + PFS : NS - 1);   // chunk tail: harmless re-read keeps the count
             }
         }
     } else {
@@ -379,7 +383,7 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
     if constexpr (STV != 0) {
         using SS = StaticShape<STV>;
         if (p.KD == SS::KD && p.KH == SS::KH && p.KW == SS::KW && p.lgTW == SS::LW && p.lgTH == SS::LH && p.lgTD == SS::LD &&
-            p.Cin % CK == 0)
+            p.nchunks % (CK / 32) == 0)
             return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, STV>(p, st);
     }
     return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, 0>(p, st);
@@ -388,7 +392,7 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
 // cfg: CFG_H_* (common.h); ck: 32 or 64
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st)
 {
-    const int stv = p.KD == 1 ? 1 : (p.lgTD == 4 ? 3 : 2);      // candidate static shape for this launch
+    const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? 4 : (p.lgTD == 4 ? 3 : 2));      // candidate static shape for this launch
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
     if (cfg == CFG && mode == MODE) {                                                                    \
         if (ck == 64) return launch_halo_cfg<64, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \
@@ -407,6 +411,7 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
     HALO_CASE(CFG_H_128x16, 2, 1, 4, 1, MODE_STD, false, 1, 0)
     HALO_CASE(CFG_H_256x16, 4, 1, 4, 1, MODE_PIXSHUF, false, 0, 0)
     HALO_CASE(CFG_H_SK128x32, 8, 2, 4, 1, MODE_STD, true, 0, 0)
+    if (cfg == CFG_H_128x160 && mode == MODE_STD && ck == 32) return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 4>(p, st);
 #undef HALO_CASE
     cs_set_error("conv_halo: unsupported cfg/mode %d/%d", cfg, mode);
     return -1;

@@ -62,6 +62,7 @@ struct cs_engine {
     const float *cmp_w = nullptr, *cmp_b = nullptr;
     ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_occ, w_third, w_fourth;
     float occ_b = 0.f;
+    const float* mask_b = nullptr;
     TLayer t_l[14];
     Affine t_pre0;
     struct S3 { ConvL c1, c2; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];
@@ -355,10 +356,10 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     t.p.act0 = ACT_RELU; t.p.out0 = dhwc(e->dm_pred, FD, 64, 64, 144);
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
-    m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 32); m.p.out0_f32 = 1;
-    m.hcfg = CFG_H_SK128x32;
+    m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
+    m.hcfg = CFG_H_128x160;
     TRY(go(e, m, st));
-    TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, 32, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
+    TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
     // occlusion (dense_motion.py:98-102): depth-collapsing (16 x 7 x 1)-tap conv, 7 horizontal taps as output channels
     ConvCall oc = mk(e->w_occ, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, 1, 64, 64);
     oc.p.inD = FD; oc.p.PD = 0; oc.p.PW = 0;
@@ -618,7 +619,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     static const long lsz[6] = {65536L * 144, 16L * 1024 * 128, 16L * 256 * 256, 16L * 64 * 512, 16L * 16 * 1024, 16L * 4 * 1024};
     for (int i = 0; i < 6; ++i) A(dm_l[i], B * lsz[i]);
     A(dm_pre, B * VOX * 64); A(dm_pred, B * VOX * 144);
-    A(dm_logits, B * VOX * 32); A(dm_deform, B * VOX * 3); A(dm_occ, B * 4096);
+    A(dm_logits, B * VOX * 160); A(dm_deform, B * VOX * 3); A(dm_occ, B * 4096);
     A(kpbuf, B * 21 * 3 * 2);
     A(w_t3, B * 4096 * 256); A(seg16, B * 4096 * 256);
     A(tmask, B * 4096 * 4); A(style, 14 * 512);
@@ -695,7 +696,8 @@ extern "C" int cs_finalize_weights(cs_engine* e)
         snprintf(n, sizeof n, "W.dec%d", i); TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 3, 3, dco[i], (double)dci[i] * dco[i] * 27, &e->w_dec[i]));
     }
     TRY(get_conv(e, "W.tail", 144, 192, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
-    TRY(get_conv(e, "W.mask", 144, 32, 32, 7, 7, 7, 32, 142.0 * 22 * 343, &e->w_mask));
+    TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));
+    TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
     TRY(get_conv(e, "W.occp", 144, 16, 16, 16, 7, 1, 0, 2272.0 * 49, &e->w_occ));
     { const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
       CS_CHECK_HIP(hipMemcpy(&e->occ_b, b->p, 4, hipMemcpyDeviceToHost)); }

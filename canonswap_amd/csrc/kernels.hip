@@ -214,11 +214,15 @@ int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, h
     return 0;
 }
 
-// softmax over the 22 mask logits + deformation = sum_k mask_k * sparse_motion_k (dense_motion.py:89-94)
-// logits: fp32 [voxel][lstride]; deformation out: fp32 [N][D][H][W][3]; optional mask out [N][22][D][H][W].
-__global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict__ logits, int lstride, const float* __restrict__ kp_d,
-                                                         const float* __restrict__ kp_s, float* __restrict__ deform,
-                                                         float* __restrict__ mask_out, int N, int D, int H, int W)
+// mask conv finish + softmax over the 22 mask logits + deformation = sum_k mask_k * sparse_motion_k
+// (dense_motion.py:88-94). The 7x7x7 mask conv runs on the MFMA kernel as a (7,7,1)-tap conv whose 154 output
+// channels are (kw, c): part[voxel][kw*22+c] = sum_{kd,kh,cin} pred[d+kd-3][h+kh-3][w][cin] * Wm[c][cin][kd][kh][kw]
+// (row stride 160 floats). This kernel adds the seven horizontally shifted partials:
+//     logit_c(d,h,w) = bias_c + sum_kw part[(d,h,w+kw-3)][kw*22+c]   (zero padding in w),
+// then softmax and the motion blend. deformation out: fp32 [N][D][H][W][3]; optional mask out [N][22][D][H][W].
+__global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                         const float* __restrict__ kp_d, const float* __restrict__ kp_s,
+                                                         float* __restrict__ deform, float* __restrict__ mask_out, int N, int D, int H, int W)
 {
     const long total = (long)N * D * H * W;
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
@@ -228,10 +232,17 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
     const int d = r % D;
     const int n = r / D;
     float l[22];
-    const float4* src = (const float4*)(logits + v * lstride);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) { const float4 q = src[j]; l[j * 4] = q.x; l[j * 4 + 1] = q.y; l[j * 4 + 2] = q.z; l[j * 4 + 3] = q.w; }
-    { const float4 q = src[5]; l[20] = q.x; l[21] = q.y; }
+    for (int k = 0; k < 22; ++k) l[k] = bias[k];
+#pragma unroll
+    for (int kw = 0; kw < 7; ++kw) {
+        const int xx = x + kw - 3;
+        if ((unsigned)xx < (unsigned)W) {
+            const float2* src = (const float2*)(part + (v + kw - 3) * 160 + kw * 22);
+#pragma unroll
+            for (int j = 0; j < 11; ++j) { const float2 q = src[j]; l[2 * j] += q.x; l[2 * j + 1] += q.y; }
+        }
+    }
     float mx = l[0];
 #pragma unroll
     for (int k = 1; k < 22; ++k) mx = fmaxf(mx, l[k]);
@@ -259,10 +270,10 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
     }
 }
 
-int launch_dm_softmax(const float* logits, int lstride, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
+int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
                       int N, int D, int H, int W, hipStream_t st)
 {
-    hipLaunchKernelGGL(dm_softmax_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, logits, lstride, kp_d, kp_s,
+    hipLaunchKernelGGL(dm_softmax_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, part, bias, kp_d, kp_s,
                        deform, mask_out, N, D, H, W);
     LAUNCH_CHECK("dm_softmax");
     return 0;

@@ -133,7 +133,10 @@ def _pack_W(out, sd):
     w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
     out["W.tail.w"] = pack_conv(w, 192)
     out["W.tail.b"] = _f32(_pad(b, 144))
-    out["W.mask.w"] = pack_conv(sd[p + ".mask.weight"], 32)
+    # 7x7x7 mask conv as a (7,7,1)-tap conv with (kw, c) output channels (summed over kw by dm_softmax_kernel):
+    # w'[kw*22 + c][cin][kd][kh][0] = W[c][cin][kd][kh][kw]
+    wm = sd[p + ".mask.weight"]                                       # [22][142][7][7][7]
+    out["W.maskp.w"] = pack_conv(wm.transpose(4, 0, 1, 2, 3).reshape(154, 142, 7, 7, 1), 160)
     out["W.mask.b"] = _f32(_pad(sd[p + ".mask.bias"], 32))
     wo = sd[p + ".occlusion.weight"].reshape(142, 16, 7, 7)          # channel j = c*16 + d (dense_motion.py:100)
     # run on the MFMA conv as a depth-collapsing (KD=16, KH=7, KW=1) conv whose 7 output channels are the 7

@@ -85,7 +85,7 @@ typedef struct cs_conv_desc {
     void* out1; long out1_sN, out1_sD, out1_sH, out1_sW;
     const float* stats;       /* SPADE: [N][C][2] = (mean, 1/sqrt(var+eps)) from cs_op_chan_stats */
     int mode;                 /* 0 std, 1 T blend, 2 SPADE, 3 pixel-shuffle + sigmoid */
-    int cfg;                  /* -1 auto conv_igemm, 0..3 conv_igemm tile cfg, -2 auto conv_halo, 10..17 conv_halo tile cfg */
+    int cfg;                  /* -1 auto conv_igemm, 0..3 conv_igemm tile cfg, -2 auto conv_halo, 10..18 conv_halo tile cfg */
     int tile_w, tile_h;       /* 0 = auto */
     int ck;                   /* conv_halo channel chunk: 0 auto, 32 or 64 */
 } cs_conv_desc;

@@ -209,6 +209,7 @@ def test_conv_pixel_shuffle_sigmoid(kern):
     ("halo_256wide_ck64", 2, 128, 256, 1, 32, 32, (1, 3, 3), 64),
     ("halo_256wide_ck32", 1, 96, 512, 1, 16, 32, (1, 3, 3), 32),
     ("halo_static3d_tail_like", 1, 160, 192, 4, 16, 16, (3, 3, 3), 32),
+    ("halo_maskp_7x7x1_160", 1, 144, 160, 4, 16, 16, (7, 7, 1), 32),
     ("halo_sk_7x7x7", 1, 144, 32, 4, 16, 16, (7, 7, 7), 32),
     ("halo_sk_3x3x3_multichunk", 2, 96, 32, 8, 8, 8, (3, 3, 3), 32),
     ("halo_sk_fewsteps", 1, 32, 32, 1, 16, 16, (1, 1, 1), 32),
@@ -221,7 +222,7 @@ def test_conv_halo_variants(name, N, Cin, Cout, D, H, W, k, ck):
     b = _randn(r, Cout, scale=0.1)
     ref = _ref_conv(x, w, b, tuple(kk // 2 for kk in k))
     out = torch.zeros(N, D, H, W, Cout, dtype=torch.float32, device=DEV)
-    ops.conv(_to_cl(x).to(DEV), ops.packed_weight(w, Cout, DEV), Cout, Cout, k, bias=b.to(DEV), out0=out, cfg=16 if "_sk_" in name else -2, ck=ck)
+    ops.conv(_to_cl(x).to(DEV), ops.packed_weight(w, Cout, DEV), Cout, Cout, k, bias=b.to(DEV), out0=out, cfg=16 if "_sk_" in name else (18 if "maskp" in name else -2), ck=ck)
     torch.cuda.synchronize()
     err = ops.rel_err(_from_cl(out), ref)
     assert err < 2e-3, (name, err)
