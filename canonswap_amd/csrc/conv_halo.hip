@@ -202,7 +202,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
                 h8_t af[WPX];
 #pragma unroll
                 for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
-                wait_vmcnt_le<WCH*(PFS - 1)>();
+                // this step's fragments are followed by min(PFS-1, NS-1-st) younger steps' loads (no reloads in the chunk tail:
+                // a load whose result is never read would let the compiler reuse its destination while it is in flight)
+                const int younger = NS - 1 - st;
+                if (younger >= PFS - 1) wait_vmcnt_le<WCH*(PFS - 1)>();
+                else if (younger == 1) wait_vmcnt_le<WCH>();
+                else wait_vmcnt_le<0>();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
                         acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), af[pi],
                                                                              acc[ci][pi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                wload_at(wr[st % PFS], cc, st + PFS < NS ? st + PFS : NS - 1);   // chunk tail: harmless re-read keeps the count
+                if (st + PFS < NS) wload_at(wr[st % PFS], cc, st + PFS);
             }
         }
     } else {
