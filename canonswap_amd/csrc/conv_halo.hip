@@ -36,12 +36,13 @@ __device__ __forceinline__ void wait_vmcnt_le()
 // Static shapes (ST): the kernel extent and the position tile are compile-time constants, so the tap loop of a chunk is
 // fully unrolled: LDS window offsets become instruction immediates and all iterator arithmetic disappears.
 //   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
-//   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2
+//   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 4; };
 template <> struct StaticShape<4> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 3, LH = 3, LD = 1; };
+template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 3; };
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(const ConvParams p)
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
             if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
             if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
             if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
+            if constexpr (WCH > 4) wfrag_load<0>(dst[4], src + 2048);
         };
 
         u4_t wr[PFD][WCH];
@@ -397,11 +399,13 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
 // cfg: CFG_H_* (common.h); ck: 32 or 64
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st)
 {
-    const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? 4 : (p.lgTD == 4 ? 3 : 2));      // candidate static shape for this launch
+    // candidate static shape for this launch
+    const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? 4 : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
     if (cfg == CFG && mode == MODE) {                                                                    \
         if (ck == 64) return launch_halo_cfg<64, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \
         if (stv == 1) return launch_halo_cfg<32, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \
+        if (stv == 5 && ST3D == 2) return launch_halo_cfg<32, WPX, WCH, WVP, WVC, MODE, SK, (ST3D == 2 ? 5 : 0)>(p, st); \
         return launch_halo_cfg<32, WPX, WCH, WVP, WVC, MODE, SK, ST3D>(p, st);                           \
     }
     HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_STD, false, 1, 0)
@@ -416,7 +420,10 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
     HALO_CASE(CFG_H_128x16, 2, 1, 4, 1, MODE_STD, false, 1, 0)
     HALO_CASE(CFG_H_256x16, 4, 1, 4, 1, MODE_PIXSHUF, false, 0, 0)
     HALO_CASE(CFG_H_SK128x32, 8, 2, 4, 1, MODE_STD, true, 0, 0)
-    if (cfg == CFG_H_128x160 && mode == MODE_STD && ck == 32) return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 4>(p, st);
+    if (cfg == CFG_H_128x160 && mode == MODE_STD && ck == 32) {
+        if (stv == 4) return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 4>(p, st);
+        return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 2>(p, st);
+    }
 #undef HALO_CASE
     cs_set_error("conv_halo: unsupported cfg/mode %d/%d", cfg, mode);
     return -1;

@@ -354,6 +354,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     }
     ConvCall t = mk(e->w_tail, e->dm_l[0], dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // util.py:261-263
     t.p.act0 = ACT_RELU; t.p.out0 = dhwc(e->dm_pred, FD, 64, 64, 144);
+    t.hcfg = CFG_H_128x160;
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
@@ -695,7 +696,7 @@ extern "C" int cs_finalize_weights(cs_engine* e)
         snprintf(n, sizeof n, "W.enc%d", i); TRY(get_conv(e, n, eci[i], eco[i], eco[i], 3, 3, 3, eco[i], (double)ecr[i] * eco[i] * 27, &e->w_enc[i]));
         snprintf(n, sizeof n, "W.dec%d", i); TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 3, 3, dco[i], (double)dci[i] * dco[i] * 27, &e->w_dec[i]));
     }
-    TRY(get_conv(e, "W.tail", 144, 192, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
+    TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));
     TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
     TRY(get_conv(e, "W.occp", 144, 16, 16, 16, 7, 1, 0, 2272.0 * 49, &e->w_occ));

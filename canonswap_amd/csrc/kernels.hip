@@ -398,19 +398,27 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict_
 __global__ void __launch_bounds__(256) chan_stats_finish_kernel(const float* __restrict__ partials, int nblk, int C, int NC, double cnt_inv,
                                                                 float eps, float* __restrict__ stats)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;     // (n, c)
-    if (i >= NC) return;
+    // workgroup = 16 channels x 16 lanes over the partials; fixed-order fp64 tree -> deterministic
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;      // (n, c) flat index, NC multiple of 16
     const int n = i / C, c = i % C;
     double s = 0, ss = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* q = partials + (((long)n * nblk + b) * C + c) * 2;
-        s += q[0]; ss += q[1];
+    for (int b = bl; b < nblk; b += 16) {
+        const float2 q = *(const float2*)(partials + (((long)n * nblk + b) * C + c) * 2);
+        s += q.x; ss += q.y;
     }
-    const double mean = s * cnt_inv;
-    double var = ss * cnt_inv - mean * mean;
-    if (var < 0) var = 0;
-    stats[(long)i * 2] = (float)mean;
-    stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    red[0][bl][cl] = s; red[1][bl][cl] = ss;
+    __syncthreads();
+    if (bl == 0) {
+        s = 0; ss = 0;
+        for (int j = 0; j < 16; ++j) { s += red[0][j][cl]; ss += red[1][j][cl]; }
+        const double mean = s * cnt_inv;
+        double var = ss * cnt_inv - mean * mean;
+        if (var < 0) var = 0;
+        stats[(long)i * 2] = (float)mean;
+        stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 static inline int stats_ppb(long P, int C) { const int PL = 256 / (C / 4); return P <= 16384 ? PL * 16 : PL * 32; }
@@ -420,13 +428,13 @@ long chan_stats_partial_floats(int N, long P, int C) { return (long)N * cdiv(P, 
 int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st)
 {
     const int G = C / 4;
-    if (C % 4 || G > 256 || 256 % G) { cs_set_error("chan_stats: unsupported C=%d", C); return -1; }
+    if (C % 16 || G > 256 || 256 % G) { cs_set_error("chan_stats: unsupported C=%d", C); return -1; }
     const int ppb = stats_ppb(P, C);
     dim3 grid(cdiv(P, ppb), (unsigned)N);
     if (is_f32) hipLaunchKernelGGL(chan_stats_kernel<true>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     else hipLaunchKernelGGL(chan_stats_kernel<false>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     LAUNCH_CHECK("chan_stats");
-    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 16)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
                        1.0 / (double)P, eps, stats);
     LAUNCH_CHECK("chan_stats_finish");
     return 0;

@@ -131,7 +131,7 @@ def _pack_W(out, sd):
     q = p + ".hourglass.decoder"
     s, t = bn_affine(sd, q + ".norm")
     w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
-    out["W.tail.w"] = pack_conv(w, 192)
+    out["W.tail.w"] = pack_conv(w, 160)
     out["W.tail.b"] = _f32(_pad(b, 144))
     # 7x7x7 mask conv as a (7,7,1)-tap conv with (kw, c) output channels (summed over kw by dm_softmax_kernel):
     # w'[kw*22 + c][cin][kd][kh][0] = W[c][cin][kd][kh][kw]
