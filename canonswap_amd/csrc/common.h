@@ -33,6 +33,10 @@ struct ConvParams {
     int N, D, H, W;     // output extents (the input is addressed at (h>>up_shift, w>>up_shift))
     int inD;            // input depth extent (== D except for the depth-collapsing occlusion conv)
     int Cin;            // valid input channels (multiple of 8)
+    // grouped input channels (conv_halo, CK=32 only; 0 = off): channel chunk j lives at in + (j / cg)*in_sG + (j % cg)*32 and
+    // only the first cg_cin channels of a group exist. Used by the occlusion conv, whose "channels" are (depth, c).
+    int cg, cg_cin;
+    long in_sG;
     int nchunks;        // ceil(Cin / 32)
     int up_shift;       // nearest-neighbour up-sampling of the input folded into addressing
     int KD, KH, KW, PD, PH, PW;

@@ -119,13 +119,21 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
                                          16, 0, 0);
     };
     auto stage_halo = [&](int buf, int c0) {     // asynchronous: completion is awaited by the next __syncthreads()
+        // channel part of the source offset; grouped mode: chunk j -> group j / cg at stride in_sG
+        long coff = c0;
+        int climit = p.Cin - c0;                 // channels of this chunk that exist
+        if (CK == 32 && p.cg > 0) {
+            const int j = c0 >> 5;
+            coff = (long)(j / p.cg) * p.in_sG + (j % p.cg) * 32;
+            climit = p.cg_cin - (j % p.cg) * 32;
+        }
         if (pre) {
 #pragma unroll
             for (int j = 0; j < HI; ++j) {
                 const int q = tid + 256 * j;
                 if (q < nitems) {
-                    const bool ok = ((pmask >> j) & 1u) && (c0 + (q % SLP) * 8 < p.Cin);
-                    glds(ok ? p.in + poff[j] + c0 : p.zero, buf, 256 * j + wave * 64);
+                    const bool ok = ((pmask >> j) & 1u) && ((q % SLP) * 8 < climit);
+                    glds(ok ? p.in + poff[j] + coff : p.zero, buf, 256 * j + wave * 64);
                 }
             }
         } else if constexpr (!DB) {
@@ -134,8 +142,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
                 if (q < nitems) {
                     bool inb;
                     const long o = piece_off(q, inb);
-                    const bool ok = inb && (c0 + (q % SLP) * 8 < p.Cin);
-                    glds(ok ? p.in + o + c0 : p.zero, buf, q0 + wave * 64);
+                    const bool ok = inb && ((q % SLP) * 8 < climit);
+                    glds(ok ? p.in + o + coff : p.zero, buf, q0 + wave * 64);
                 }
             }
         }

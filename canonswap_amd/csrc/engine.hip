@@ -223,6 +223,13 @@ int pick_cfg(int Cout_pad)
     return CFG_256x16;
 }
 
+// tile configuration of the 32->32 3x3x3 convs on the [H][W][D][C] volumes (experiment knob: CANONSWAP_V32=128|256)
+int cfg_v32()
+{
+    static const int v = [] { const char* e = getenv("CANONSWAP_V32"); return (e && atoi(e) == 128) ? (int)CFG_H_128x32 : (int)CFG_H_256x32; }();
+    return v;
+}
+
 bool halo_enabled()
 {
     static const bool on = getenv("CANONSWAP_NO_HALO") == nullptr;
@@ -253,7 +260,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         const bool is3d = c.p.KD > 1;
         if (!prefW) { prefW = is3d ? 8 : 16; prefH = is3d ? 8 : BM / 16; }
         set_tile(c.p, BM, prefW, prefH);
-        const int ck = (!is3d && c.p.Cin % 64 == 0) ? 64 : 32;
+        const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0) ? 64 : 32;
         return e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl);
     }
     if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
@@ -287,7 +294,7 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
         ConvCall c1 = mk(rb[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);   // conv1 with norm2 folded, ReLU
         c1.p.act0 = ACT_RELU;
         c1.p.out0 = hwdc3(e->va[1]);
-        c1.hcfg = CFG_H_256x32;
+        c1.hcfg = cfg_v32();
         TRY(go(e, c1, st, 4, 4));
         const int nxt = (*cur + 1) % 3;
         ConvCall c2 = mk(rb[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);   // conv2 + x
@@ -296,7 +303,7 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
         c2.p.out1 = hwdc3(e->va[0]);
         if (i < 5) { c2.p.s2 = rb[i].post.s; c2.p.t2 = rb[i].post.t; c2.p.act1 = ACT_RELU; }
         else if (final_post) { c2.p.s2 = final_post->s; c2.p.t2 = final_post->t; c2.p.act1 = final_act; }
-        c2.hcfg = CFG_H_256x32;
+        c2.hcfg = cfg_v32();
         TRY(go(e, c2, st, 4, 4));
         *cur = nxt;
     }
@@ -361,11 +368,18 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     m.hcfg = CFG_H_128x160;
     TRY(go(e, m, st));
     TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
-    // occlusion (dense_motion.py:98-102): depth-collapsing (16 x 7 x 1)-tap conv, 7 horizontal taps as output channels
-    ConvCall oc = mk(e->w_occ, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, 1, 64, 64);
-    oc.p.inD = FD; oc.p.PD = 0; oc.p.PW = 0;
+    // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose
+    // input channels are grouped by depth slice (16 groups of 144 channels at stride sD) and whose 7 output channels are the
+    // 7 horizontal taps (summed by occ_finish_kernel).
+    ConvCall oc = mk(e->w_occ, e->dm_pred, td(nullptr, (long)FD * 4096 * 144, 0, 64L * 144, 144), B, 1, 64, 64);
+    oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
     oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 16); oc.p.out0_f32 = 1;
-    TRY(go(e, oc, st));
+    if (halo_enabled()) {
+        TRY(go(e, oc, st));
+    } else {
+        cs_set_error("the occlusion conv needs conv_halo (grouped input channels)");
+        return -1;
+    }
     TRY(e->run(1, st, [&] { return launch_occ_finish(e->dm_occpart, e->occ_b, e->dm_occ, B, 64, 64, st); }, "occ_finish"));
     return 0;
 }
@@ -427,7 +441,7 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
         ConvCall c1 = mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
-        c1.hcfg = CFG_H_256x32;
+        c1.hcfg = cfg_v32();
         TRY(go(e, c1, st, 4, 4));
         float* s1;
         TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s1, st));
@@ -435,7 +449,7 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
                                                        e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }, "norm_act"));
         ConvCall c2 = mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
-        c2.hcfg = CFG_H_256x32;
+        c2.hcfg = cfg_v32();
         TRY(go(e, c2, st, 4, 4));
         float* s2;
         TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s2, st));
@@ -699,7 +713,7 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));
     TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
-    TRY(get_conv(e, "W.occp", 144, 16, 16, 16, 7, 1, 0, 2272.0 * 49, &e->w_occ));
+    TRY(get_conv(e, "W.occp", 16 * 160, 16, 16, 1, 7, 1, 0, 2272.0 * 49, &e->w_occ));
     { const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
       CS_CHECK_HIP(hipMemcpy(&e->occ_b, b->p, 4, hipMemcpyDeviceToHost)); }
     TRY(get_conv(e, "W.third", 512, 256, 256, 1, 3, 3, 256, 512.0 * 256 * 9, &e->w_third));

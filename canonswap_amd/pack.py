@@ -139,9 +139,12 @@ def _pack_W(out, sd):
     out["W.maskp.w"] = pack_conv(wm.transpose(4, 0, 1, 2, 3).reshape(154, 142, 7, 7, 1), 160)
     out["W.mask.b"] = _f32(_pad(sd[p + ".mask.bias"], 32))
     wo = sd[p + ".occlusion.weight"].reshape(142, 16, 7, 7)          # channel j = c*16 + d (dense_motion.py:100)
-    # run on the MFMA conv as a depth-collapsing (KD=16, KH=7, KW=1) conv whose 7 output channels are the 7
-    # horizontal taps kx (finished by occ_finish_kernel): w[kx][c][d][ky][0] = W_occ[0][c*16+d][ky][kx]
-    out["W.occp.w"] = pack_conv(wo.transpose(3, 0, 1, 2)[..., None], 16)
+    # run on the MFMA conv as a 2-D (KH=7, KW=1) conv over grouped channels: input channel d*160 + c (c < 144 real) is depth
+    # slice d, channel c; the 7 output channels are the horizontal taps kx (summed by occ_finish_kernel):
+    #   w'[kx][d*160 + c][ky][0] = W_occ[0][c*16 + d][ky][kx]
+    wg = np.zeros((7, 16, 160, 7, 1), np.float32)
+    wg[:, :, :142, :, 0] = wo.transpose(3, 1, 0, 2)                  # [kx][d][c][ky]
+    out["W.occp.w"] = pack_conv(wg.reshape(7, 16 * 160, 7, 1), 16)
     out["W.occ.b"] = _f32(sd[p + ".occlusion.bias"].reshape(1))
     s, t = bn_affine(sd, "third.norm")
     w, b = fold_conv_bn(sd["third.conv.weight"][:, MEM2REF], sd["third.conv.bias"], s, t)
