@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "8")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "16")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -136,9 +136,16 @@ def main():
                          "kernel": "conv_halo + conv_igemm (every convolution launch)", "launches_per_step": prof["conv_launches"] // K,
                          "avg_launch_us": round(prof["conv_ms"] * 1e3 / prof["conv_launches"], 2),
                          "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * B) / 1e9, 1),
-                         "other_kernels_ms_per_step": round(prof["other_ms"] / K, 3),
+                         "other_kernels_ms_per_step": round((prof["other_ms"] + prof["warp_ms"]) / K, 3),
                          "conv_ms_per_step": round(prof["conv_ms"] / K, 3),
                          "end_to_end_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / world / (PEAK_TFLOPS_F16 * 1e12), 4)},
+            # the HBM-bound row of the path: trilinear feature warp (F.grid_sample, warping_network.py:46-47), fp32 volumes:
+            # algorithmic bytes per frame and call = 8.39 MB in + 0.79 MB grid + 8.39 MB out (+ 4.19 MB fp16 copy on the first call)
+            "warp_roofline": {"bound": "hbm", "kernel": "grid_sample_kernel",
+                              "achieved": round((2 * 17.56e6 + 4.19e6) * B * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
+                              "peak": 8000.0, "unit": "GB/s",
+                              "frac": round((2 * 17.56e6 + 4.19e6) * B * K / (prof["warp_ms"] / 1e3) / 8e12, 4),
+                              "avg_launch_us": round(prof["warp_ms"] * 1e3 / max(prof["warp_launches"], 1), 2), "traffic": None},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -814,7 +814,7 @@ extern "C" int cs_warp(cs_engine* e, int B, const float* f, const float* kp_sour
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
     TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, e->vs[1], nullptr, B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, e->vs[1], nullptr, B, FD, FH, FW, st); }, "grid_sample"));
     TRY(from_hwdc(e, B, e->vs[1], f_out, st));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
     return 0;
@@ -857,7 +857,7 @@ extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float*
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
     TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     if (seg_out) TRY(e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }, "nhwc16_to_nchw"));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
@@ -891,7 +891,7 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
     // :244 warp(f_s, kp_source = x_t, kp_driving = x_can)
     TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_can, /*kp_s*/ x_t, nullptr, st));
     const int nxt = (cur + 1) % 3;
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, e->vs[nxt], e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, e->vs[nxt], e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
     cur = nxt;
     // the first warp's occlusion map is reused by the debug decodes (:248,:257); keep a copy in tmask-free storage
     float* occ1 = e->img_b;   // B*4096 floats fit easily
@@ -908,7 +908,7 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
     TRY(run_R(e, B, &cur, st));                                                             // :262
     // :263 warp_decode(f, kp_source = x_can, kp_driving = x_t)
     TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_t, /*kp_s*/ x_can, nullptr, st));
-    TRY(e->run(1, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     float* dst = out_f32 ? out_f32 : e->img_a;
     TRY(run_G(e, B, e->seg16, dst, st));
@@ -923,11 +923,11 @@ extern "C" int cs_profile_begin(cs_engine* e)
     return 0;
 }
 
-extern "C" int cs_profile_end(cs_engine* e, double ms[2], long counts[2], double* flops)
+extern "C" int cs_profile_end(cs_engine* e, double ms[3], long counts[3], double* flops)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
     CS_CHECK_HIP(hipDeviceSynchronize());
-    ms[0] = ms[1] = 0; counts[0] = counts[1] = 0;
+    ms[0] = ms[1] = ms[2] = 0; counts[0] = counts[1] = counts[2] = 0;
     FILE* csv = nullptr;
     if (const char* path = getenv("CANONSWAP_PROFILE_CSV")) csv = fopen(path, "w");
     if (csv) fprintf(csv, "family,label,ms,gflop\n");

@@ -64,9 +64,10 @@ int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float*
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream */
 int cs_profile_begin(cs_engine* e);
-/* ms[0] = conv_igemm kernels, ms[1] = all other kernels; counts likewise; flops = algorithmic conv FLOPs
- * (2*MAC over the reference's logical channel counts) enqueued since cs_profile_begin */
-int cs_profile_end(cs_engine* e, double ms[2], long counts[2], double* flops);
+/* ms[0] = convolution kernels (conv_halo / conv_igemm), ms[1] = all other kernels except ms[2] = the feature warp
+ * (grid_sample_kernel); counts likewise; flops = algorithmic conv FLOPs (2*MAC over the reference's logical channel
+ * counts) enqueued since cs_profile_begin. CANONSWAP_PROFILE_CSV=<path> additionally dumps one line per launch. */
+int cs_profile_end(cs_engine* e, double ms[3], long counts[3], double* flops);
 
 /* ---- operator level (unit parity tests) ---------------------------------------------------------------- */
 typedef struct cs_conv_desc {
