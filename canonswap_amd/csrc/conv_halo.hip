@@ -177,14 +177,13 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
         constexpr int PFS = NS < 3 ? NS : 3;      // weight ring depth; the ring is re-primed at every chunk
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
         u4_t wr[PFS][WCH];
+        // In this fully unrolled body hipcc counts vmcnt / lgkmcnt exactly (the only conservative drain sits at the chunk
+        // loop's back-edge, next to the barrier), so the weight fragments are ordinary loads here.
         auto wload_at = [&](u4_t (&dst)[WCH], int cc, int st) {          // st: compile-time after unrolling
-            const int ccl = cc < nck ? cc : nck - 1;                      // past the end: harmless re-read
+            const int ccl = cc < nck ? cc : nck - 1;
             const half_t* src = wlane + (long)((ccl * KH32 + st % KH32) * NT + st / KH32) * wstep;
-            wfrag_load<0>(dst[0], src);
-            if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
-            if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
-            if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
-            if constexpr (WCH > 4) wfrag_load<0>(dst[4], src + 2048);
+#pragma unroll
+            for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const u4_t*)(src + ci * 512);
         };
         stage_halo(0, 0);
         __syncthreads();
@@ -204,25 +203,40 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
                 }
             }
             const unsigned char* hb = smem + (size_t)(DB ? (cc & 1) : 0) * HV * VS;
+            // Software-pipelined operand fetch: the position fragments are split in two halves; while the MFMAs of one half
+            // run, the ds_reads of the other half (of this step or of the next one) are in flight, so no LDS round trip is
+            // exposed in steady state and no extra registers are needed.
+            constexpr int HA = WPX / 2;                    // fragments in the first half
+            auto toff_of = [&](int st) -> int {
+                const int tap = st / KH32, half = st % KH32;
+                return (((tap / (SS::KW * SS::KH)) * SHH + (tap / SS::KW) % SS::KH) * SHW + tap % SS::KW) * VS + half * 64;
+            };
+            h8_t afA[HA > 0 ? HA : 1], afB[WPX - HA];
+#pragma unroll
+            for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + abase[pi] + toff_of(0));
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
-                const int tap = st / KH32, half = st % KH32;
-                const int toff = (((tap / (SS::KW * SS::KH)) * SHH + (tap / SS::KW) % SS::KH) * SHW + tap % SS::KW) * VS + half * 64;
-                h8_t af[WPX];
+                const int toff = toff_of(st);
 #pragma unroll
-                for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
-                // this step's fragments are followed by min(PFS-1, NS-1-st) younger steps' loads (no reloads in the chunk tail:
-                // a load whose result is never read would let the compiler reuse its destination while it is in flight)
-                const int younger = NS - 1 - st;
-                if (younger >= PFS - 1) wait_vmcnt_le<WCH*(PFS - 1)>();
-                else if (younger == 1) wait_vmcnt_le<WCH>();
-                else wait_vmcnt_le<0>();
+                for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + abase[pi] + toff);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
 #pragma unroll
-                    for (int pi = 0; pi < WPX; ++pi)
-                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), af[pi],
+                    for (int pi = 0; pi < HA; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afA[pi],
+                                                                             acc[ci][pi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NS) {
+#pragma unroll
+                    for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + abase[pi] + toff_of(st + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+                    for (int pi = HA; pi < WPX; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afB[pi - HA],
                                                                              acc[ci][pi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + PFS < NS) wload_at(wr[st % PFS], cc, st + PFS);
@@ -318,10 +332,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
         }
     }
 
-    // The ring still has untracked loads in flight (re-reads issued by the last PFD steps): drain them before the
-    // compiler reuses those VGPRs in the epilogue.
-    wait_vmcnt_le<0>();
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ST == 0) {
+        // The asm ring still has untracked loads in flight (re-reads issued by the last PFD steps): drain them before the
+        // compiler reuses those VGPRs in the epilogue.
+        wait_vmcnt_le<0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     if constexpr (!SK) {
         constexpr int EP_WPX = WPX;
