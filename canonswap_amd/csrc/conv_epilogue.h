@@ -39,6 +39,23 @@ __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, con
 // lgS, mW, mH, mD, wch, l15, l4 and the template constants WCH, BM, MODE.
 #define CONV_EPILOGUE() \
     constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
+    /* per-channel constants of this lane's 4 channels, loaded once (16-byte loads), not once per position block */ \
+    float4 ep_bias[WCH], ep_bias2[WCH], ep_s2[WCH], ep_t2[WCH], ep_mean[WCH], ep_rstd[WCH]; \
+_Pragma("unroll") \
+    for (int ci = 0; ci < WCH; ci += CSTEP) { \
+        const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
+        const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+        const bool cok = cb < p.Cout; \
+        ep_bias[ci] = (cok && p.bias) ? *(const float4*)(p.bias + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
+        ep_bias2[ci] = (cok && MODE == MODE_SPADE) ? *(const float4*)(p.bias2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
+        ep_s2[ci] = (cok && p.s2) ? *(const float4*)(p.s2 + cb) : make_float4(1.f, 1.f, 1.f, 1.f); \
+        ep_t2[ci] = (cok && p.s2) ? *(const float4*)(p.t2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
+        if (MODE == MODE_SPADE && cok) { /* SPADE launches tile within one sample: n == tn */ \
+            const float4 q0 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb) * 2); \
+            const float4 q1 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb) * 2 + 4); \
+            ep_mean[ci] = make_float4(q0.x, q0.z, q1.x, q1.z); ep_rstd[ci] = make_float4(q0.y, q0.w, q1.y, q1.w); \
+        } else { ep_mean[ci] = make_float4(0.f, 0.f, 0.f, 0.f); ep_rstd[ci] = make_float4(1.f, 1.f, 1.f, 1.f); } \
+    } \
 _Pragma("unroll") \
     for (int pi = 0; pi < EP_WPX; ++pi) { \
         int m = ep_wpx * EP_WPX * 16 + pi * 16 + l15; \
@@ -58,7 +75,7 @@ _Pragma("unroll") \
             if (MODE == MODE_TBLEND) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) \
-                    v[r] = ps * (ep_acc[ci + CSTEP - 1][pi][r] + p.bias[cb + r]) + (1.f - ps) * ep_acc[ci][pi][r]; \
+                    v[r] = ps * (ep_acc[ci + CSTEP - 1][pi][r] + ((const float*)&ep_bias[ci])[r]) + (1.f - ps) * ep_acc[ci][pi][r]; \
             } else if (MODE == MODE_SPADE) { \
                 float x[4]; \
                 const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> p.res_shift) * p.res.sH + \
@@ -66,14 +83,13 @@ _Pragma("unroll") \
                 load4(p.res, p.res_f32, xo, x); \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
-                    const float* st = p.stats + ((long)n * p.Cout + cb + r) * 2; \
-                    const float g = ep_acc[ci][pi][r] + p.bias[cb + r]; \
-                    const float b = ep_acc[ci + CSTEP - 1][pi][r] + p.bias2[cb + r]; \
-                    v[r] = (x[r] - st[0]) * st[1] * (1.f + g) + b; \
+                    const float g = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
+                    const float b = ep_acc[ci + CSTEP - 1][pi][r] + ((const float*)&ep_bias2[ci])[r]; \
+                    v[r] = (x[r] - ((const float*)&ep_mean[ci])[r]) * ((const float*)&ep_rstd[ci])[r] * (1.f + g) + b; \
                 } \
             } else { \
 _Pragma("unroll") \
-                for (int r = 0; r < 4; ++r) v[r] = ep_acc[ci][pi][r] + (p.bias ? p.bias[cb + r] : 0.f); \
+                for (int r = 0; r < 4; ++r) v[r] = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
             } \
 _Pragma("unroll") \
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act0, p.slope0); \
@@ -104,7 +120,7 @@ _Pragma("unroll") \
                 float u[4]; \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
-                    const float a = p.s2 ? v[r] * p.s2[cb + r] + p.t2[cb + r] : v[r]; \
+                    const float a = v[r] * ((const float*)&ep_s2[ci])[r] + ((const float*)&ep_t2[ci])[r]; \
                     u[r] = apply_act(a, p.act1, p.slope1); \
                 } \
                 store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u); \

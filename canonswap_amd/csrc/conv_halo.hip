@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
     constexpr int SL = CK / 8;           // 16-byte slots per voxel
     constexpr int SLP = SL + 1;          // ... plus one pad slot (bank spreading; also fetched, from the zero page)
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
-    constexpr int HI = 8;                // halo pieces per thread whose source offsets are kept in registers
+    // halo pieces per thread whose source offsets are kept in registers (the big halos of the mask conv / 4x4x16 tiles too)
+    constexpr int HI = ST == 4 ? 18 : (ST == 3 ? 13 : 8);
     constexpr int KH32 = CK / 32;        // 32-channel K-steps per tap and chunk
     constexpr int PFD = 4;               // weight prefetch depth in K-steps
     constexpr int SKS = SK ? 4 : 1;      // K-step stride of one wave
@@ -384,6 +385,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if (p.inD != p.D) { cs_set_error("conv_halo: depth-collapsing convs are not supported"); return -1; }
     const int lgS = p.lgTW + p.lgTH + p.lgTD;
     if ((1 << lgS) > BM) { cs_set_error("conv_halo: spatial tile exceeds BM"); return -1; }
+    if (MODE == MODE_SPADE && (1 << lgS) != BM) { cs_set_error("conv_halo: SPADE launches must tile within one sample"); return -1; }
     const int TN = BM >> lgS;
     const long HV = (long)TN * ((1 << p.lgTD) + p.KD - 1) * ((1 << p.lgTH) + p.KH - 1) * ((1 << p.lgTW) + p.KW - 1);
     const int nck = (p.Cin + CK - 1) / CK;

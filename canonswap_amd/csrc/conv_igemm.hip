@@ -152,6 +152,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t st)
     constexpr int BM = WPX * 16 * WVP, BN = WCH * 16 * WVC;
     if (p.Cout_pad % BN != 0) { cs_set_error("conv: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
     if ((1 << (p.lgTW + p.lgTH + p.lgTD)) > BM) { cs_set_error("conv: spatial tile exceeds BM"); return -1; }
+    if (MODE == MODE_SPADE && (1 << (p.lgTW + p.lgTH + p.lgTD)) != BM) { cs_set_error("conv: SPADE launches must tile within one sample"); return -1; }
     const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(half_t);
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
     hipLaunchKernelGGL((conv_igemm_kernel<WPX, WCH, WVP, WVC, MODE>), grid, dim3(256), lds, st, p);

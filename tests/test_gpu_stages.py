@@ -135,3 +135,46 @@ def test_errors_are_loud(swapper):
         swapper.extract_feature_3d(torch.zeros(1, 3, 128, 128).cuda())
     with pytest.raises(ValueError):
         swapper.extract_feature_3d(torch.zeros(9, 3, 256, 256).cuda())        # > max_batch
+
+
+def test_stage_api_equals_fused_loop(swapper, case):
+    """Calling the reference's stage methods one by one (with fp32 NCDHW tensors in between) gives the same image as
+    the fused loop body: the only difference is where fp16 conv-input copies are derived, so agreement is to ~65 dB."""
+    from oracle import canonswap_ref as O
+    args, idv, _ = case
+    img, x_t, x_can, sid = args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), idv.cuda()
+    f_s = swapper.extract_feature_3d(img)
+    f_can, occ = swapper.warping_module.warp(f_s, x_t, x_can)
+    f_swap = swapper.swap_module(f_can, sid)
+    f_ref = swapper.refine_module(f_swap)
+    out = swapper.warp_decode(f_ref, x_can, x_t)["out"]
+    fused = swapper.swap_frames(img, x_t, x_can, sid)["out"]
+    assert O.psnr(out.cpu(), fused.cpu()) > 60.0
+
+
+def test_non_contiguous_and_cpu_inputs_are_accepted(swapper, case):
+    args, idv, _ = case
+    img = args["img"][:1]
+    a = swapper.extract_feature_3d(img.cuda())
+    b = swapper.extract_feature_3d(img)                                   # CPU tensor: moved to the engine's device
+    c = swapper.extract_feature_3d(img.cuda().permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2))   # strided view
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_swap_without_identity_is_an_error(state_dicts):
+    from canonswap_amd.can_swap_e2e import can_swapper
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=1)
+    with pytest.raises(RuntimeError, match="cs_set_identity"):
+        sw.engine.swap(torch.zeros(1, 32, 16, 64, 64).cuda())
+    sw.engine.close()
+
+
+def test_missing_weights_are_an_error():
+    from canonswap_amd import _lib
+    from canonswap_amd.engine import Engine
+    e = Engine(0, max_batch=1)
+    with pytest.raises(RuntimeError, match="was not uploaded"):
+        _lib.check(e.lib.cs_finalize_weights(e.h), "cs_finalize_weights")
+    with pytest.raises(RuntimeError, match="cs_finalize_weights has not been called"):
+        e.extract_feature_3d(torch.zeros(1, 3, 256, 256).cuda())
+    e.close()
