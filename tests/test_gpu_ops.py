@@ -127,7 +127,7 @@ def test_conv_hwdc_residual_dual_output(kern):
     assert ops.rel_err(back(out1), y2) < 3e-3
 
 
-@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("kern", KERNELS + ["halo256"])
 def test_conv_tblend(kern):
     """Fused [W ; w_mod] conv + blend epilogue == AdaptiveSharedWeightConv2d (adaptive_modulate.py:139-186)."""
     import hip_ops as ops
@@ -147,19 +147,19 @@ def test_conv_tblend(kern):
     out = torch.zeros(N, 1, H, W, Cc, dtype=torch.float32, device=DEV)
     resd = res.permute(0, 2, 3, 1).contiguous().unsqueeze(1).to(DEV)
     ops.conv(_to_cl(x).to(DEV), wp, 2 * Cc, Cc, (1, 3, 3), bias=bias.to(DEV), pixscale=m4, ps_stride=4, res=resd, out0=out, mode=1,
-             cfg=_cfg(kern, 0, 10))
+             cfg=17 if kern == "halo256" else _cfg(kern, 0, 10))
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 2e-3
 
 
-@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("kern", KERNELS + ["halo256"])
 @pytest.mark.parametrize("xshift", [0, 1])
 def test_conv_spade(xshift, kern):
     """gamma/beta convs + instance-norm modulation epilogue == SPADE.forward (util.py:295-302) + leaky_relu(0.2)."""
     import hip_ops as ops
     from canonswap_amd import pack
     r = _rng(14 + xshift)
-    N, Cc, S = 2, 64, 32
+    N, Cc, S = 2, (128 if kern == "halo256" else 64), 32
     Sx = S >> xshift
     actv = _randn(r, N, 128, S, S)
     x = _randn(r, N, Cc, Sx, Sx) * 2 + 0.5
@@ -173,10 +173,10 @@ def test_conv_spade(xshift, kern):
     ref = F.leaky_relu(xn * (1 + F.conv2d(aq, wg.half().float(), bg, padding=1)) + F.conv2d(aq, wb.half().float(), bb, padding=1), 0.2)
     xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
     stats = ops.chan_stats(xd.reshape(N, Sx * Sx, Cc))
-    wp = torch.from_numpy(pack.pack_conv(pack.interleave16(wg.numpy(), wb.numpy()), 128)).to(DEV)
+    wp = torch.from_numpy(pack.pack_conv(pack.interleave16(wg.numpy(), wb.numpy()), 2 * Cc)).to(DEV)
     out = torch.zeros(N, 1, S, S, Cc, dtype=torch.float16, device=DEV)
-    ops.conv(_to_cl(actv).to(DEV), wp, 128, Cc, (1, 3, 3), bias=bg.to(DEV), bias2=bb.to(DEV), res=xd.unsqueeze(1), res_shift=xshift,
-             stats=stats, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=_cfg(kern, 0, 10))
+    ops.conv(_to_cl(actv).to(DEV), wp, 2 * Cc, Cc, (1, 3, 3), bias=bg.to(DEV), bias2=bb.to(DEV), res=xd.unsqueeze(1), res_shift=xshift,
+             stats=stats, act0="lrelu", slope0=0.2, out0=out, mode=2, cfg=17 if kern == "halo256" else _cfg(kern, 0, 10))
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
 
