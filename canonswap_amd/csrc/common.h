@@ -7,7 +7,6 @@ typedef _Float16 half_t;
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
-typedef float f16v_t __attribute__((ext_vector_type(16)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
 enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3 };

@@ -128,93 +128,3 @@ _Pragma("unroll") \
         } \
     } \
 
-// Epilogue for the v_mfma_f32_32x32x16_f16 kernels. Accumulator layout (weights as the A operand):
-// ep_acc[cj][pj][4*q + r] is channel row (8*q + 4*l5 + r) of 32-row block cj, position column (lane & 31) of 32-position
-// block pj. With the interleave16 row packing of the paired modes (TBLEND / SPADE) a 32-row block is [16 first | 16 second]
-// operand rows, so quads q = 0,1 pair with quads q+2 in the same lane.
-// Expects in scope: p, ep_acc[WC32][WP32] (f16v_t), n0, tw, th, td, tn, lgS, mW, mH, mD, wch32 (first 32-row block of this
-// wave), l31, l5 and the template constants WC32, WP32, BM, MODE.
-#define CONV_EPILOGUE32() \
-    constexpr bool PAIRED = (MODE == MODE_TBLEND || MODE == MODE_SPADE); \
-    constexpr int NQ = PAIRED ? 2 : 4; \
-    float4 ep_bias[WC32][NQ], ep_bias2[WC32][NQ], ep_s2[WC32][NQ], ep_t2[WC32][NQ], ep_mean[WC32][NQ], ep_rstd[WC32][NQ]; \
-_Pragma("unroll") \
-    for (int cj = 0; cj < WC32; ++cj) \
-_Pragma("unroll") \
-        for (int q = 0; q < NQ; ++q) { \
-            const int pb32 = n0 / 32 + wch32 + cj; \
-            const int cb = (PAIRED ? pb32 * 16 : pb32 * 32) + 8 * q + 4 * l5; \
-            const bool cok = cb < p.Cout; \
-            ep_bias[cj][q] = (cok && p.bias) ? *(const float4*)(p.bias + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
-            ep_bias2[cj][q] = (cok && MODE == MODE_SPADE) ? *(const float4*)(p.bias2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
-            ep_s2[cj][q] = (cok && p.s2) ? *(const float4*)(p.s2 + cb) : make_float4(1.f, 1.f, 1.f, 1.f); \
-            ep_t2[cj][q] = (cok && p.s2) ? *(const float4*)(p.t2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
-            if (MODE == MODE_SPADE && cok) { \
-                const float4 q0 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb) * 2); \
-                const float4 q1 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb) * 2 + 4); \
-                ep_mean[cj][q] = make_float4(q0.x, q0.z, q1.x, q1.z); ep_rstd[cj][q] = make_float4(q0.y, q0.w, q1.y, q1.w); \
-            } else { ep_mean[cj][q] = make_float4(0.f, 0.f, 0.f, 0.f); ep_rstd[cj][q] = make_float4(1.f, 1.f, 1.f, 1.f); } \
-        } \
-_Pragma("unroll") \
-    for (int pj = 0; pj < WP32; ++pj) { \
-        int m = pj * 32 + l31; \
-        const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
-        const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
-        const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD; \
-        const int n = tn * (BM >> lgS) + m; \
-        if (n >= p.N) continue; \
-        float ps = 1.f; \
-        if (p.pixscale) ps = p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
-_Pragma("unroll") \
-        for (int cj = 0; cj < WC32; ++cj) \
-_Pragma("unroll") \
-            for (int q = 0; q < NQ; ++q) { \
-                const int pb32 = n0 / 32 + wch32 + cj; \
-                const int cb = (PAIRED ? pb32 * 16 : pb32 * 32) + 8 * q + 4 * l5; \
-                if (cb >= p.Cout) continue; \
-                float v[4]; \
-                if (MODE == MODE_TBLEND) { \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) \
-                        v[r] = ps * (ep_acc[cj][pj][4 * (q + 2) + r] + ((const float*)&ep_bias[cj][q])[r]) + \
-                               (1.f - ps) * ep_acc[cj][pj][4 * q + r]; \
-                } else if (MODE == MODE_SPADE) { \
-                    float x[4]; \
-                    const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> p.res_shift) * p.res.sH + \
-                                    (long)(w >> p.res_shift) * p.res.sW + cb; \
-                    load4(p.res, p.res_f32, xo, x); \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) { \
-                        const float g = ep_acc[cj][pj][4 * q + r] + ((const float*)&ep_bias[cj][q])[r]; \
-                        const float b = ep_acc[cj][pj][4 * (q + 2) + r] + ((const float*)&ep_bias2[cj][q])[r]; \
-                        v[r] = (x[r] - ((const float*)&ep_mean[cj][q])[r]) * ((const float*)&ep_rstd[cj][q])[r] * (1.f + g) + b; \
-                    } \
-                } else { \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) v[r] = ep_acc[cj][pj][4 * q + r] + ((const float*)&ep_bias[cj][q])[r]; \
-                } \
-_Pragma("unroll") \
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act0, p.slope0); \
-                if (MODE != MODE_SPADE && p.res.p) { \
-                    float rr[4]; \
-                    load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)h * p.res.sH + (long)w * p.res.sW + cb, rr); \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
-                } \
-                if (MODE == MODE_STD && p.pixscale) { \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) v[r] *= ps; \
-                } \
-                if (p.out0.p) \
-                    store4(p.out0, p.out0_f32, (long)n * p.out0.sN + (long)d * p.out0.sD + (long)h * p.out0.sH + (long)w * p.out0.sW + cb, v); \
-                if (p.out1.p) { \
-                    float u[4]; \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) { \
-                        const float a = v[r] * ((const float*)&ep_s2[cj][q])[r] + ((const float*)&ep_t2[cj][q])[r]; \
-                        u[r] = apply_act(a, p.act1, p.slope1); \
-                    } \
-                    store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u); \
-                } \
-            } \
-    }

@@ -17,7 +17,6 @@
 // LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes.
 #include "common.h"
 #include "conv_epilogue.h"
-#include <cstdlib>
 
 // Weight fragments are streamed with loads the compiler does not track (inline asm) and are waited for with an
 // explicit counted s_waitcnt: hipcc drains vmcnt to 0 at every loop back-edge for loads it tracks, which would
@@ -377,197 +376,6 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(cons
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 32x32x16 variant of the static 2-D 3x3 kernel (tile 16x8 positions, every wave covers all 128 positions and WC32*32
-// channels, 4 waves side by side in channels). v_mfma_f32_32x32x16_f16 moves 4x fewer operand registers per FLOP than
-// the 16x16x32 form (higher sustained clock) and its 32-position operand fetch spreads over LDS banks better.
-// K-slot convention of a lane (both operands): lane group l5 = lane>>5 holds channels l5*16 + kh*8 + j of the 32-channel
-// K-step (kh = which of the two k16 MFMAs, j = 0..7) -- one contiguous 32 bytes per lane for weights and activations.
-template <int CK, int WC32, int MODE, bool DB>
-__global__ void __launch_bounds__(256, 2) conv_halo32_kernel(const ConvParams p)
-{
-    using SS = StaticShape<1>;
-    constexpr int WP32 = 4;              // 128 positions per wave
-    constexpr int BM = 128, BN = WC32 * 32 * 4;
-    constexpr int SL = CK / 8, SLP = SL + 1, VS = SLP * 16, HI = 8, KH32 = CK / 32;
-    constexpr int NT = 9, NS = NT * KH32, PFS = 3;
-    constexpr int HW = 18, HH = 10, HV = HW * HH;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, l5 = lane >> 5;
-    const int wch32 = wave * WC32;       // first 32-row block of this wave inside the workgroup's channel tile
-    int t = blockIdx.x;
-    const int tw = t % p.nTW; t /= p.nTW;
-    const int th = t % p.nTH; t /= p.nTH;
-    const int td = 0; t /= p.nTD;
-    const int tn = t;
-    const int n0 = blockIdx.y * BN;
-    constexpr int lgS = 7;
-    constexpr int mW = 15, mH = 7, mD = 0;
-    const int nitems = HV * SLP;
-    const int w0 = tw << 4, h0 = th << 3;
-
-    auto piece_off = [&](int q, bool& inb) -> long {
-        const int hv = q / SLP;
-        const int hw = hv % HW, hh = hv / HW;
-        const int ih = h0 + hh - 1, iw = w0 + hw - 1;
-        inb = q < nitems && (q % SLP) < SL && tn < p.N && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        return (long)tn * p.in_sN + (long)(ih >> p.up_shift) * p.in_sH + (long)(iw >> p.up_shift) * p.in_sW + (q % SLP) * 8;
-    };
-    int poff[HI];
-    unsigned pmask = 0;
-#pragma unroll
-    for (int j = 0; j < HI; ++j) {
-        bool inb;
-        const long o = piece_off(tid + 256 * j, inb);
-        poff[j] = inb ? (int)o : 0;
-        pmask |= inb ? (1u << j) : 0u;
-    }
-    auto stage_halo = [&](int buf, int c0) {
-#pragma unroll
-        for (int j = 0; j < HI; ++j) {
-            const int q = tid + 256 * j;
-            if (q < nitems) {
-                const bool ok = ((pmask >> j) & 1u) && ((q % SLP) * 8 < p.Cin - c0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? p.in + poff[j] + c0 : p.zero),
-                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)buf * HV * VS + (size_t)(256 * j + wave * 64) * 16),
-                                                 16, 0, 0);
-            }
-        }
-    };
-
-    int abase[WP32];
-#pragma unroll
-    for (int pj = 0; pj < WP32; ++pj) {
-        const int m = pj * 32 + l31;
-        abase[pj] = ((m >> 4) * HW + (m & 15)) * VS + l5 * 32;
-    }
-    // weights: 32-row block cj of K-step kidx = 2 KiB at wgt + (kidx*Cout_pad + n0 + (wch32+cj)*32)*32; lane = (row l31, 16 k at l5*16)
-    const half_t* wlane = p.wgt + ((long)(n0 + wch32 * 32 + l31) * 32 + l5 * 16);
-    const long wstep = (long)p.Cout_pad * 32;
-    const int nck = p.Cin / CK;
-
-    f16v_t acc[WC32][WP32];
-#pragma unroll
-    for (int cj = 0; cj < WC32; ++cj)
-#pragma unroll
-        for (int pj = 0; pj < WP32; ++pj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cj][pj][r] = 0.f;
-
-    u4_t wr[PFS][WC32][2];               // [slot][32-row block][k16 half]
-    auto wload_at = [&](u4_t (&dst)[WC32][2], int cc, int st) {
-        const half_t* src = wlane + (long)((cc * KH32 + st % KH32) * NT + st / KH32) * wstep;
-#pragma unroll
-        for (int cj = 0; cj < WC32; ++cj) {
-            dst[cj][0] = *(const u4_t*)(src + cj * 1024);
-            dst[cj][1] = *(const u4_t*)(src + cj * 1024 + 8);
-        }
-    };
-    auto toff_of = [&](int st) -> int {
-        const int tap = st / KH32, half = st % KH32;
-        return ((tap / 3) * HW + tap % 3) * VS + half * 64;
-    };
-    stage_halo(0, 0);
-    __syncthreads();
-    if (DB && nck > 1) stage_halo(1, CK);
-    for (int cc = 0; cc < nck; ++cc) {
-#pragma unroll
-        for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
-        if (cc > 0) {
-            if (DB) {
-                __syncthreads();
-                if (cc + 1 < nck) stage_halo((cc + 1) & 1, (cc + 1) * CK);
-            } else {
-                __syncthreads();
-                stage_halo(0, cc * CK);
-                __syncthreads();
-            }
-        }
-        const unsigned char* hb = smem + (size_t)(DB ? (cc & 1) : 0) * HV * VS;
-        // software pipeline over half steps: position blocks {0,1} and {2,3}
-        h8_t afA[2][2], afB[2][2];       // [position block][k16 half]
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            afA[j][0] = *(const h8_t*)(hb + abase[j] + toff_of(0));
-            afA[j][1] = *(const h8_t*)(hb + abase[j] + toff_of(0) + 16);
-        }
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int toff = toff_of(st);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                afB[j][0] = *(const h8_t*)(hb + abase[2 + j] + toff);
-                afB[j][1] = *(const h8_t*)(hb + abase[2 + j] + toff + 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cj = 0; cj < WC32; ++cj)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
-                        acc[cj][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[st % PFS][cj][kh]), afA[j][kh],
-                                                                           acc[cj][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (st + 1 < NS) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    afA[j][0] = *(const h8_t*)(hb + abase[j] + toff_of(st + 1));
-                    afA[j][1] = *(const h8_t*)(hb + abase[j] + toff_of(st + 1) + 16);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cj = 0; cj < WC32; ++cj)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int kh = 0; kh < 2; ++kh)
-                        acc[cj][2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[st % PFS][cj][kh]), afB[j][kh],
-                                                                               acc[cj][2 + j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (st + PFS < NS) wload_at(wr[st % PFS], cc, st + PFS);
-        }
-    }
-    auto& ep_acc = acc;
-    CONV_EPILOGUE32()
-}
-
-template <int CK, int WC32, int MODE>
-static int launch_halo32(const ConvParams& p, hipStream_t st)
-{
-    constexpr int BN = WC32 * 128, SLP = CK / 8 + 1, VS = SLP * 16, HV = 180;
-    const int nck = p.Cin / CK;
-    const bool db = nck > 1;
-    const size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
-    dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
-    if (db) hipLaunchKernelGGL((conv_halo32_kernel<CK, WC32, MODE, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_halo32_kernel<CK, WC32, MODE, false>), grid, dim3(256), lds, st, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { cs_set_error("conv_halo32 launch: %s", hipGetErrorString(e)); return -1; }
-    return 0;
-}
-
-static bool use_mfma32()
-{
-    static const bool on = getenv("CANONSWAP_NO_MFMA32") == nullptr;
-    return on;
-}
-
-// 2-D 3x3, tile 16x8, Cin a multiple of the chunk, channel tile 128 (WC32=1) or 256 (WC32=2)
-static bool halo32_eligible(const ConvParams& p, int cfg, int ck, int mode)
-{
-    if (!use_mfma32()) return false;
-    if (cfg != CFG_H_128x128 && cfg != CFG_H_128x256) return false;
-    if (mode != MODE_STD && mode != MODE_TBLEND && mode != MODE_SPADE) return false;
-    if (p.KD != 1 || p.KH != 3 || p.KW != 3 || p.lgTW != 4 || p.lgTH != 3 || p.lgTD != 0 || p.D != 1) return false;
-    if (p.Cin % ck != 0 || p.cg != 0) return false;
-    return p.Cout_pad % (cfg == CFG_H_128x256 ? 256 : 128) == 0;
-}
-
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK, int ST>
 static int launch_halo_st(const ConvParams& p, hipStream_t st)
 {
@@ -617,13 +425,6 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
 // cfg: CFG_H_* (common.h); ck: 32 or 64
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st)
 {
-    if (halo32_eligible(p, cfg, ck, mode)) {
-#define H32_CASE(CKV, WC, MODE) if (ck == CKV && (cfg == CFG_H_128x256 ? 2 : 1) == WC && mode == MODE) return launch_halo32<CKV, WC, MODE>(p, st);
-        H32_CASE(64, 2, MODE_STD) H32_CASE(64, 2, MODE_TBLEND) H32_CASE(64, 2, MODE_SPADE)
-        H32_CASE(64, 1, MODE_STD) H32_CASE(64, 1, MODE_SPADE)
-        H32_CASE(32, 2, MODE_STD) H32_CASE(32, 1, MODE_STD)
-#undef H32_CASE
-    }
     // candidate static shape for this launch
     const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? 4 : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
