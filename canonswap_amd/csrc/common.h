@@ -9,7 +9,8 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
-enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3 };
+enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3,
+       MODE_STDSTAT = 4 };   // MODE_STD + per-tile channel statistics of the stored output (selected by the launchers when p.stat_out)
 // tile configurations of conv_igemm (pixels x channels per 256-thread workgroup)
 enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
 // tile configurations of conv_halo
@@ -65,6 +66,10 @@ struct ConvParams {
     float slope1;
     TDesc out1;
     const float* stats;     // SPADE: [N][C][2] = (mean, 1/sqrt(var+eps)) of x over its H*W
+    // optional: per-(sample, tile, channel) partial (sum, sum of squares) of the stored out0 values, for the next layer's
+    // Instance/GroupNorm: stat_out[((n*nblk + blk)*Cout + c)*2 + {0,1}], nblk = tiles per sample * waves along positions.
+    // Finished by launch_chan_stats_finish (fixed order: deterministic). Requires tiles that lie within one sample.
+    float* stat_out;
 };
 
 #define CS_CHECK_HIP(expr)                                                                  \
@@ -94,6 +99,7 @@ int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, i
 int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);
 int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st);
 long chan_stats_partial_floats(int N, long P, int C);
+int launch_chan_stats_finish(const float* partials, int nblk, int N, int C, double cnt_inv, float eps, float* stats, hipStream_t st);
 int launch_norm_act(const float* y, const float* stats, const float* gamma, const float* beta,
                     const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
                     int act2, float slope2, int N, long per_n, hipStream_t st);

@@ -56,6 +56,13 @@ _Pragma("unroll") \
             ep_mean[ci] = make_float4(q0.x, q0.z, q1.x, q1.z); ep_rstd[ci] = make_float4(q0.y, q0.w, q1.y, q1.w); \
         } else { ep_mean[ci] = make_float4(0.f, 0.f, 0.f, 0.f); ep_rstd[ci] = make_float4(1.f, 1.f, 1.f, 1.f); } \
     } \
+    constexpr bool EP_STAT = (MODE == MODE_STDSTAT); /* compile-time: the accumulators cost occupancy otherwise */ \
+    constexpr int EP_SC = EP_STAT ? WCH : 1; \
+    float ep_sum[EP_SC][4], ep_sq[EP_SC][4]; \
+_Pragma("unroll") \
+    for (int ci = 0; ci < EP_SC; ++ci) \
+_Pragma("unroll") \
+        for (int r = 0; r < 4; ++r) { ep_sum[ci][r] = 0.f; ep_sq[ci][r] = 0.f; } \
 _Pragma("unroll") \
     for (int pi = 0; pi < EP_WPX; ++pi) { \
         int m = ep_wpx * EP_WPX * 16 + pi * 16 + l15; \
@@ -110,12 +117,19 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
             } \
-            if (MODE == MODE_STD && p.pixscale) { \
+            if ((MODE == MODE_STD || MODE == MODE_STDSTAT) && p.pixscale) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \
             if (p.out0.p) \
                 store4(p.out0, p.out0_f32, (long)n * p.out0.sN + (long)d * p.out0.sD + (long)h * p.out0.sH + (long)w * p.out0.sW + cb, v); \
+            if (EP_STAT) { /* statistics of the values as stored (fp16-rounded when out0 is fp16) */ \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) { \
+                    const float vs = p.out0_f32 ? v[r] : (float)(half_t)v[r]; \
+                    ep_sum[EP_STAT ? ci : 0][r] += vs; ep_sq[EP_STAT ? ci : 0][r] = fmaf(vs, vs, ep_sq[EP_STAT ? ci : 0][r]); \
+                } \
+            } \
             if (p.out1.p) { \
                 float u[4]; \
 _Pragma("unroll") \
@@ -127,4 +141,25 @@ _Pragma("unroll") \
             } \
         } \
     } \
+    if (EP_STAT) { /* fixed-order butterfly over the 16 position lanes, then one partial per (tile, wave, channel) */ \
+        const int ep_tiles = p.nTW * p.nTH * p.nTD; \
+        const int ep_nblk = ep_tiles * (BM / (EP_WPX * 16)); \
+        const int ep_blk = (blockIdx.x % ep_tiles) * (BM / (EP_WPX * 16)) + ep_wpx; \
+_Pragma("unroll") \
+        for (int ci = 0; ci < WCH; ci += CSTEP) { \
+            const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
+            const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; ++r) { \
+                float a = ep_sum[EP_STAT ? ci : 0][r], b = ep_sq[EP_STAT ? ci : 0][r]; \
+_Pragma("unroll") \
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); } \
+                if (l15 == 0 && cb < p.Cout) { \
+                    float* dst = p.stat_out + (((long)tn * ep_nblk + ep_blk) * p.Cout + cb + r) * 2; \
+                    dst[0] = a; dst[1] = b; \
+                } \
+            } \
+        } \
+    }
+
 

@@ -426,6 +426,7 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st)
 {
     // candidate static shape for this launch
+    if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
     const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? 4 : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
     if (cfg == CFG && mode == MODE) {                                                                    \
@@ -438,6 +439,10 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
     HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_TBLEND, false, 1, 0)
     HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_SPADE, false, 1, 0)
     HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_STD, false, 1, 2)
+    HALO_CASE(CFG_H_128x256, 8, 4, 1, 4, MODE_STDSTAT, false, 1, 0)
+    HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_STDSTAT, false, 1, 0)
+    HALO_CASE(CFG_H_128x64, 4, 2, 2, 2, MODE_STDSTAT, false, 1, 0)
+    HALO_CASE(CFG_H_256x32, 4, 2, 4, 1, MODE_STDSTAT, false, 0, 3)
     HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_TBLEND, false, 1, 0)
     HALO_CASE(CFG_H_128x128, 8, 2, 1, 4, MODE_SPADE, false, 1, 0)
     HALO_CASE(CFG_H_128x64, 4, 2, 2, 2, MODE_STD, false, 1, 2)

@@ -163,7 +163,13 @@ static int launch_cfg(const ConvParams& p, hipStream_t st)
 
 int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st)
 {
-    if (mode == MODE_STD) {
+    if (mode == MODE_STD && p.stat_out) {
+        switch (cfg) {
+        case CFG_128x128: return launch_cfg<4, 4, 2, 2, MODE_STDSTAT>(p, st);
+        case CFG_128x64: return launch_cfg<2, 4, 4, 1, MODE_STDSTAT>(p, st);
+        case CFG_256x32: return launch_cfg<4, 2, 4, 1, MODE_STDSTAT>(p, st);
+        }
+    } else if (mode == MODE_STD) {
         switch (cfg) {
         case CFG_128x128: return launch_cfg<4, 4, 2, 2, MODE_STD>(p, st);
         case CFG_128x64: return launch_cfg<2, 4, 4, 1, MODE_STD>(p, st);

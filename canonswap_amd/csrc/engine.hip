@@ -180,6 +180,7 @@ struct ConvCall {
     ConvParams p;
     int cfg = -1, mode = MODE_STD;
     int hcfg = -1;            // forced conv_halo configuration (else derived from Cout_pad)
+    int stat_nblk = 0;        // set by go(): partial blocks per sample when p.stat_out is used
     double macs_per_pos = 0;
     const char* name = "";
 };
@@ -260,6 +261,12 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         const bool is3d = c.p.KD > 1;
         if (!prefW) { prefW = is3d ? 8 : 16; prefH = is3d ? 8 : BM / 16; }
         set_tile(c.p, BM, prefW, prefH);
+        {   // positions covered by one wave in the epilogue -> partial-statistics blocks per sample
+            int wave_px = 128;
+            if (hcfg == CFG_H_128x64 || hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_128x160) wave_px = 64;
+            if (hcfg == CFG_H_128x32 || hcfg == CFG_H_128x16 || hcfg == CFG_H_SK128x32) wave_px = 32;
+            c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (BM / wave_px);
+        }
         const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0) ? 64 : 32;
         return e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl);
     }
@@ -267,7 +274,23 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
     if (!prefW) { prefW = 16; prefH = BM / 16; }
     set_tile(c.p, BM, prefW, prefH);
+    c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (c.cfg == CFG_128x128 ? 2 : 4);
     return e->run(0, st, [&] { return launch_conv(c.p, c.cfg, c.mode, st); }, c.name, fl);
+}
+
+float* stats_slot(cs_engine* e);
+
+// Convolution whose epilogue also emits the Instance/GroupNorm partial sums of its stored output; returns the finished
+// (mean, rstd) slot. P = positions per sample.
+int go_stats(cs_engine* e, ConvCall& c, int C, long P, float** slot, hipStream_t st, int prefW = 0, int prefH = 0)
+{
+    c.p.stat_out = e->stats_part;
+    TRY(go(e, c, st, prefW, prefH));
+    float* s = stats_slot(e);
+    *slot = s;
+    const int nblk = c.stat_nblk, N = c.p.N;
+    if ((long)nblk * C * 2 > 262144) { cs_set_error("%s: statistics partials do not fit (%d blocks x %d)", c.name, nblk, C); return -1; }
+    return e->run(1, st, [&] { return launch_chan_stats_finish(e->stats_part, nblk, N, C, 1.0 / (double)P, 1e-5f, s, st); }, "chan_stats_finish");
 }
 
 float* stats_slot(cs_engine* e)
@@ -442,17 +465,15 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
         ConvCall c1 = mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
         c1.hcfg = cfg_v32();
-        TRY(go(e, c1, st, 4, 4));
         float* s1;
-        TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s1, st));
+        TRY(go_stats(e, c1, 32, VOX, &s1, st, 4, 4));
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
                                                        e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }, "norm_act"));
         ConvCall c2 = mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
         c2.hcfg = cfg_v32();
-        TRY(go(e, c2, st, 4, 4));
         float* s2;
-        TRY(do_stats(e, e->vs[y], 1, B, VOX, 32, &s2, st));
+        TRY(go_stats(e, c2, 32, VOX, &s2, st, 4, 4));
         const bool pre = (i == 2 && last_pre);
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s2, blk[i].g2, blk[i].b2, e->vs[*cur], 0.01f,
                                                        e->vs[nxt], e->va[0], pre ? last_pre->s : nullptr, pre ? last_pre->t : nullptr,
@@ -504,7 +525,8 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
 {
     ConvCall fc = mk(e->g_fc, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
     fc.p.out0 = nhwc(e->g_x[0], 64, 64, 512);
-    TRY(go(e, fc, st));
+    float* sx = nullptr;             // (mean, rstd) of the current x, produced by the epilogue of the conv that wrote it
+    TRY(go_stats(e, fc, 512, 4096, &sx, st));
     // all 18 mlp_shared convs depend only on seg (util.py:298): three fused launches
     ConvCall s64 = mk(e->g_sh64, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
     s64.p.act0 = ACT_RELU; s64.p.out0 = nhwc(e->g_a64, 64, 64, 1536);
@@ -519,27 +541,22 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     int cx = 0;
     for (int b = 0; b < 6; ++b) {   // SPADEResnetBlock 512->512 @64x64 (util.py:329-344)
         const cs_engine::SpadeBlk& K = e->g_blk[b];
-        float* st0;
-        TRY(do_stats(e, e->g_x[cx], 0, B, 4096, 512, &st0, st));
-        TRY(spade_gb(e, K.n0, 512, e->g_a64, 1536, (b * 2) * 128, B, 64, e->g_x[cx], 0, st0, ACT_LRELU, e->g_h64, st));
+        TRY(spade_gb(e, K.n0, 512, e->g_a64, 1536, (b * 2) * 128, B, 64, e->g_x[cx], 0, sx, ACT_LRELU, e->g_h64, st));
         ConvCall c0 = mk(K.c0, e->g_h64, nhwc(nullptr, 64, 64, 512), B, 1, 64, 64);
         c0.p.out0 = nhwc(e->g_dx64, 64, 64, 512);
-        TRY(go(e, c0, st));
         float* st1;
-        TRY(do_stats(e, e->g_dx64, 0, B, 4096, 512, &st1, st));
+        TRY(go_stats(e, c0, 512, 4096, &st1, st));
         TRY(spade_gb(e, K.n1, 512, e->g_a64, 1536, (b * 2 + 1) * 128, B, 64, e->g_dx64, 0, st1, ACT_LRELU, e->g_h64, st));
         ConvCall c1 = mk(K.c1, e->g_h64, nhwc(nullptr, 64, 64, 512), B, 1, 64, 64);
         c1.p.res = nhwc(e->g_x[cx], 64, 64, 512);
         c1.p.out0 = nhwc(e->g_x[cx ^ 1], 64, 64, 512);
-        TRY(go(e, c1, st));
+        TRY(go_stats(e, c1, 512, 4096, &sx, st));
         cx ^= 1;
     }
     // up_0: nn.Upsample(x2) folded into addressing; 512 -> 256 @128 (learned shortcut)
     {
         const cs_engine::SpadeBlk& K = e->g_blk[6];
-        const half_t* x = e->g_x[cx];
-        float* sx;     // nearest up-sampling leaves per-channel mean / variance unchanged
-        TRY(do_stats(e, x, 0, B, 4096, 512, &sx, st));
+        const half_t* x = e->g_x[cx];   // nearest up-sampling leaves per-channel mean / variance unchanged: sx still applies
         TRY(spade_gb(e, K.ns, 512, e->g_a128, 384, 256, B, 128, x, 1, sx, ACT_NONE, e->g_h128, st));
         ConvCall cs = mk(K.cs, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
         cs.p.out0 = nhwc(e->g_xs128, 128, 128, 256);
@@ -547,21 +564,18 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
         TRY(spade_gb(e, K.n0, 512, e->g_a128, 384, 0, B, 128, x, 1, sx, ACT_LRELU, e->g_h128, st));
         ConvCall c0 = mk(K.c0, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
         c0.p.out0 = nhwc(e->g_dx128, 128, 128, 256);
-        TRY(go(e, c0, st));
         float* s1;
-        TRY(do_stats(e, e->g_dx128, 0, B, 16384, 256, &s1, st));
+        TRY(go_stats(e, c0, 256, 16384, &s1, st));
         TRY(spade_gb(e, K.n1, 256, e->g_a128, 384, 128, B, 128, e->g_dx128, 0, s1, ACT_LRELU, e->g_h1_128, st));
         ConvCall c1 = mk(K.c1, e->g_h1_128, nhwc(nullptr, 128, 128, 256), B, 1, 128, 128);
         c1.p.res = nhwc(e->g_xs128, 128, 128, 256);
         c1.p.out0 = nhwc(e->g_o128, 128, 128, 256);
-        TRY(go(e, c1, st));
+        TRY(go_stats(e, c1, 256, 16384, &sx, st));
     }
     // up_1: 256 -> 64 @256
     {
         const cs_engine::SpadeBlk& K = e->g_blk[7];
         const half_t* x = e->g_o128;
-        float* sx;
-        TRY(do_stats(e, x, 0, B, 16384, 256, &sx, st));
         TRY(spade_gb(e, K.ns, 256, e->g_a256, 384, 256, B, 256, x, 1, sx, ACT_NONE, e->g_h256, st));
         ConvCall cs = mk(K.cs, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
         cs.p.out0 = nhwc(e->g_xs256, 256, 256, 64);
@@ -569,9 +583,8 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
         TRY(spade_gb(e, K.n0, 256, e->g_a256, 384, 0, B, 256, x, 1, sx, ACT_LRELU, e->g_h256, st));
         ConvCall c0 = mk(K.c0, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
         c0.p.out0 = nhwc(e->g_dx256, 256, 256, 64);
-        TRY(go(e, c0, st));
         float* s1;
-        TRY(do_stats(e, e->g_dx256, 0, B, 65536, 64, &s1, st));
+        TRY(go_stats(e, c0, 64, 65536, &s1, st));
         TRY(spade_gb(e, K.n1, 64, e->g_a256, 384, 128, B, 256, e->g_dx256, 0, s1, ACT_LRELU, e->g_h1_256, st));
         ConvCall c1 = mk(K.c1, e->g_h1_256, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
         c1.p.res = nhwc(e->g_xs256, 256, 256, 64);

@@ -425,6 +425,14 @@ static inline int stats_ppb(long P, int C) { const int PL = 256 / (C / 4); retur
 
 long chan_stats_partial_floats(int N, long P, int C) { return (long)N * cdiv(P, stats_ppb(P, C)) * C * 2; }
 
+int launch_chan_stats_finish(const float* partials, int nblk, int N, int C, double cnt_inv, float eps, float* stats, hipStream_t st)
+{
+    if (C % 16) { cs_set_error("chan_stats_finish: unsupported C=%d", C); return -1; }
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 16)), dim3(256), 0, st, partials, nblk, C, N * C, cnt_inv, eps, stats);
+    LAUNCH_CHECK("chan_stats_finish");
+    return 0;
+}
+
 int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st)
 {
     const int G = C / 4;
