@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "16")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "32")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -37,12 +37,14 @@ __device__ __forceinline__ void wait_vmcnt_le()
 // fully unrolled: LDS window offsets become instruction immediates and all iterator arithmetic disappears.
 //   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
 //   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
+//   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 4; };
 template <> struct StaticShape<4> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 3; };
+template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(const ConvParams p)
@@ -427,7 +429,7 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
 {
     // candidate static shape for this launch
     if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
-    const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? 4 : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
+    const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? (p.lgTW == 1 ? 6 : 4) : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
     if (cfg == CFG && mode == MODE) {                                                                    \
         if (ck == 64) return launch_halo_cfg<64, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \
@@ -453,6 +455,7 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
     HALO_CASE(CFG_H_SK128x32, 8, 2, 4, 1, MODE_STD, true, 0, 0)
     if (cfg == CFG_H_128x160 && mode == MODE_STD && ck == 32) {
         if (stv == 4) return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 4>(p, st);
+        if (stv == 6) return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 6>(p, st);
         return launch_halo_cfg<32, 4, 5, 2, 2, MODE_STD, false, 2>(p, st);
     }
 #undef HALO_CASE

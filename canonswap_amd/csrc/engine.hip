@@ -389,7 +389,10 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
     m.hcfg = CFG_H_128x160;
-    TRY(go(e, m, st));
+    {   // no halo along W (KW = 1): a 2x8x8 tile stages 392 halo voxels per 128 positions, 8x8x2 would stage 896
+        static const bool wide = getenv("CANONSWAP_MASK_TILE8") != nullptr;
+        TRY(go(e, m, st, wide ? 8 : 2, 8));
+    }
     TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
     // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose
     // input channels are grouped by depth slice (16 groups of 144 channels at stride sD) and whose 7 output channels are the

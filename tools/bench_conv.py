@@ -14,20 +14,17 @@ import hip_ops as ops  # noqa: E402
 DEV = "cuda:0"
 # name, N, Cin, Cout_pad, D, H, W, k, up_shift, halo cfg, tile, real_flop_factor
 SHAPES = [
-    ("T fused 512->1024 3x3 @64 B8", 8, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
-    ("T fused 512->1024 3x3 (128x128)", 8, 512, 1024, 1, 64, 64, (1, 3, 3), 0, 10, (0, 0)),
-    ("G conv 512->512 3x3 @64 B8", 8, 512, 512, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
-    ("G gb 128->1024 3x3 @64 B8", 8, 128, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
-    ("G gb 128->512 3x3 @256 B4", 4, 128, 512, 1, 256, 256, (1, 3, 3), 0, -2, (0, 0)),
+    ("T fused 512->1024 3x3 @64 B16", 16, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("G conv 512->512 3x3 @64 B16", 16, 512, 512, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("G gb 128->1024 3x3 @64 B16", 16, 128, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("G gb 128->512 3x3 @128 B16", 16, 128, 512, 1, 128, 128, (1, 3, 3), 0, -2, (0, 0)),
     ("G shared 256->384 3x3 @256 B4", 4, 256, 384, 1, 256, 256, (1, 3, 3), 0, -2, (0, 0)),
-    ("W mask 144->32 7x7x7 B2", 2, 144, 32, 16, 64, 64, (7, 7, 7), 0, 16, (8, 8)),
-    ("W mask 144->32 7x7x7 B2 noSK", 2, 144, 32, 16, 64, 64, (7, 7, 7), 0, 13, (8, 8)),
-    ("W tail 144->192 3x3x3 B2", 2, 144, 192, 16, 64, 64, (3, 3, 3), 0, -2, (8, 8)),
-    ("W enc0 112->64 3x3x3 B4", 4, 112, 64, 16, 64, 64, (3, 3, 3), 0, -2, (8, 8)),
-    ("W dec0 1024->512 3x3x3 @4 up B8", 8, 1024, 512, 16, 4, 4, (3, 3, 3), 1, -2, (8, 8)),
-    ("W dec1 1024->256 3x3x3 @8 up B8", 8, 1024, 256, 16, 8, 8, (3, 3, 3), 1, -2, (8, 8)),
-    ("3D 32->32 3x3x3 hwdc-like B8", 8, 32, 32, 16, 64, 64, (3, 3, 3), 0, 12, (4, 4)),
-    ("3D 32->32 3x3x3 SK B8", 8, 32, 32, 16, 64, 64, (3, 3, 3), 0, 16, (8, 8)),
+    ("W maskp 144->160 7x7x1 B8", 8, 144, 160, 16, 64, 64, (7, 7, 1), 0, 18, (2, 8)),
+    ("W tail 144->160 3x3x3 B8", 8, 144, 160, 16, 64, 64, (3, 3, 3), 0, 18, (8, 8)),
+    ("W enc0 112->64 3x3x3 B8", 8, 112, 64, 16, 64, 64, (3, 3, 3), 0, -2, (8, 8)),
+    ("W dec4 128->32 3x3x3 up B8", 8, 128, 32, 16, 64, 64, (3, 3, 3), 1, -2, (8, 8)),
+    ("W dec1 1024->256 3x3x3 @8 up B16", 16, 1024, 256, 16, 8, 8, (3, 3, 3), 1, -2, (8, 8)),
+    ("3D 32->32 3x3x3 hwdc-like B16", 16, 32, 32, 16, 64, 64, (3, 3, 3), 0, 12, (4, 4)),
 ]
 
 
@@ -43,7 +40,7 @@ def run(name, N, Cin, Cout, D, H, W, k, us, hcfg, tile, kern):
     for _ in range(2):
         ops.conv(x, wp, Cout, Cout, k, **args)
     torch.cuda.synchronize()
-    n = 5
+    n = 20
     t = time.perf_counter()
     for _ in range(n):
         ops.conv(x, wp, Cout, Cout, k, **args)
@@ -59,7 +56,7 @@ def main():
         if only and only not in s[0]:
             continue
         res = []
-        for kern in ("igemm", "halo"):
+        for kern in (("igemm", "halo") if os.environ.get("BENCH_IGEMM") else ("halo",)):
             try:
                 ms, tf = run(*s, kern)
                 res.append("%s %7.3f ms %7.1f TF/s" % (kern, ms, tf))
