@@ -76,8 +76,11 @@ class can_swapper(object):
             self.load_state_dicts(combined)
 
     def load_state_dicts(self, combined: dict):
-        self.engine.load_state_dicts({k: combined[k] for k in
-                                      ("appearance_feature_extractor", "warping_module", "spade_generator", "transfer", "refine")})
+        keys = ["appearance_feature_extractor", "warping_module", "spade_generator", "transfer", "refine"]
+        if "motion_extractor" in combined:
+            keys.append("motion_extractor")
+            self.motion_extractor = _Callable(self.engine.motion_extract)
+        self.engine.load_state_dicts({k: combined[k] for k in keys})
 
     # ---- small helpers kept for interface parity
     def inference_ctx(self):
@@ -92,7 +95,17 @@ class can_swapper(object):
         raise NotImplementedError("ArcFace identity extraction is outside the generator hot path; pass source_id (1x512)")
 
     def get_kp_info(self, x, **kwargs):
-        raise NotImplementedError("motion extractor M is outside the generator hot path (SURVEY.md section 8f, N1)")
+        """can_swap_e2e.py:174-199: implicit key-point information of Bx3x256x256 images in [0,1]."""
+        if self.motion_extractor is None:
+            raise RuntimeError("get_kp_info: the loaded weights hold no 'motion_extractor' state-dict")
+        kp_info = self.motion_extractor(x)
+        if kwargs.get("flag_refine_info", True):
+            bs = kp_info["kp"].shape[0]
+            for k in ("pitch", "yaw", "roll"):
+                kp_info[k] = headpose_pred_to_degree(kp_info[k])[:, None]
+            kp_info["kp"] = kp_info["kp"].reshape(bs, -1, 3)
+            kp_info["exp"] = kp_info["exp"].reshape(bs, -1, 3)
+        return kp_info
 
     # ---- data preparation (:126-163)
     def prepare_source(self, img: np.ndarray) -> torch.Tensor:

@@ -8,7 +8,7 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };   // GELU: exact erf form (nn.GELU default)
 enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3,
        MODE_STDSTAT = 4 };   // MODE_STD + per-tile channel statistics of the stored output (selected by the launchers when p.stat_out)
 // tile configurations of conv_igemm (pixels x channels per 256-thread workgroup)
@@ -112,3 +112,10 @@ int launch_t_style(const float* id, const float* fc, float* style, int nlayers, 
 int launch_t_modulate(const float* wraw, const float* style, half_t* packed, int layer, hipStream_t st);
 int launch_pack_u8(const float* img, uint8_t* out, int N, int C, int H, int W, hipStream_t st);
 int launch_lrelu16(const half_t* in, half_t* out, long n, float slope, hipStream_t st);
+
+// ---- motion extractor pieces (motion.hip)
+int launch_m_stem(const float* img, const float* w, const float* b, const float* g, const float* be, float* x, int N, int HI, int WI, hipStream_t st);
+int launch_m_dwln(const float* x, const float* wt, const float* b, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st);
+int launch_m_ln_s2d(const float* x, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st);
+int launch_m_grn(const float* h, const float* gamma, const float* beta, float* sumsq, float* scale, half_t* out, int N, int P, int C, hipStream_t st);
+int launch_m_head(const float* x, const float* g, const float* be, const float* hw, const float* hb, float* out, int N, int P, hipStream_t st);

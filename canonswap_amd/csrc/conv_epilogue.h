@@ -9,6 +9,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
     if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     return v;
 }
 

@@ -71,6 +71,16 @@ struct cs_engine {
     struct GB { ConvL conv; const float *bg, *bb; };
     struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs; bool learned; int fin, fmid, fout; } g_blk[8];
 
+    // motion extractor (optional: present when the "M.*" blobs were uploaded)
+    bool has_m = false;
+    const float *m_stem_w = nullptr, *m_stem_b = nullptr, *m_stem_g = nullptr, *m_stem_be = nullptr;
+    struct MBlk { const float *dw_w, *dw_b, *ln_g, *ln_b, *grn_g, *grn_b; ConvL pw1, pw2; };
+    struct MStage { int C, n; MBlk blk[9]; const float *ds_g, *ds_b; ConvL ds; } m_st[4];
+    const float *m_norm_g = nullptr, *m_norm_b = nullptr, *m_head_w = nullptr, *m_head_b = nullptr;
+    float *m_x = nullptr, *m_sumsq = nullptr, *m_scale = nullptr;
+    half_t *m_y = nullptr, *m_h = nullptr;   // split-precision GEMM operands [hi | lo | hi]
+    float* m_h32 = nullptr;
+
     // ---- workspace
     half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
     float* vs[3]; half_t* va[2];
@@ -611,6 +621,44 @@ int check(cs_engine* e, int B)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ M
+// MotionExtractor.forward (motion_extractor.py:33-35 -> convnextv2.py:110-144): img fp32 NCHW 256x256 -> raw head outputs [B][328]
+int run_M(cs_engine* e, int B, const float* img, float* out, hipStream_t st)
+{
+    if (!e->has_m) { cs_set_error("the motion extractor weights (M.*) were not uploaded"); return -1; }
+    if (!e->m_x) {   // workspace on first use
+        const size_t P0 = (size_t)e->maxB * 64 * 64;
+        if (e->alloc(&e->m_x, P0 * 96) || e->alloc(&e->m_y, P0 * 96 * 3) || e->alloc(&e->m_h, P0 * 384 * 3) || e->alloc(&e->m_h32, P0 * 384) ||
+            e->alloc(&e->m_sumsq, (size_t)e->maxB * 3072) || e->alloc(&e->m_scale, (size_t)e->maxB * 3072)) return -1;
+    }
+    TRY(e->run(1, st, [&] { return launch_m_stem(img, e->m_stem_w, e->m_stem_b, e->m_stem_g, e->m_stem_be, e->m_x, B, 256, 256, st); }, "m_stem"));
+    int H = 64;
+    for (int i = 0; i < 4; ++i) {
+        const cs_engine::MStage& S = e->m_st[i];
+        const int C = S.C;
+        for (int j = 0; j < S.n; ++j) {
+            const cs_engine::MBlk& K = S.blk[j];
+            TRY(e->run(1, st, [&] { return launch_m_dwln(e->m_x, K.dw_w, K.dw_b, K.ln_g, K.ln_b, e->m_y, B, H, H, C, st); }, "m_dwln"));
+            ConvCall a = mk(K.pw1, e->m_y, nhwc(nullptr, H, H, 3 * C), B, 1, H, H);              // convnextv2.py:39-40
+            a.p.act0 = ACT_GELU; a.p.out0 = nhwc(e->m_h32, H, H, 4 * C); a.p.out0_f32 = 1;
+            TRY(go(e, a, st));
+            TRY(e->run(1, st, [&] { return launch_m_grn(e->m_h32, K.grn_g, K.grn_b, e->m_sumsq, e->m_scale, e->m_h, B, H * H, 4 * C, st); }, "m_grn"));
+            ConvCall b = mk(K.pw2, e->m_h, nhwc(nullptr, H, H, 12 * C), B, 1, H, H);             // :42 + residual :45
+            b.p.res = nhwc(e->m_x, H, H, C); b.p.res_f32 = 1;
+            b.p.out0 = nhwc(e->m_x, H, H, C); b.p.out0_f32 = 1;
+            TRY(go(e, b, st));
+        }
+        if (i < 3) {   // downsample_layers[i+1]: LayerNorm + Conv2d(k=2, s=2) as space-to-depth + 1x1 conv
+            TRY(e->run(1, st, [&] { return launch_m_ln_s2d(e->m_x, S.ds_g, S.ds_b, e->m_y, B, H, H, C, st); }, "m_ln_s2d"));
+            H /= 2;
+            ConvCall d = mk(S.ds, e->m_y, nhwc(nullptr, H, H, 12 * C), B, 1, H, H);
+            d.p.out0 = nhwc(e->m_x, H, H, 2 * C); d.p.out0_f32 = 1;
+            TRY(go(e, d, st));
+        }
+    }
+    return e->run(1, st, [&] { return launch_m_head(e->m_x, e->m_norm_g, e->m_norm_b, e->m_head_w, e->m_head_b, out, B, H * H, st); }, "m_head");
+}
+
 int copy_dd(void* dst, const void* src, size_t bytes, hipStream_t st)
 {
     hipError_t r = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
@@ -701,6 +749,36 @@ extern "C" int cs_finalize_weights(cs_engine* e)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
     char n[96];
+    // ---- M (optional)
+    e->has_m = e->find("M.stem.w") != nullptr;
+    if (e->has_m) {
+        static const int dims[4] = {96, 192, 384, 768}, depths[4] = {3, 3, 9, 3};
+        TRY(get_f32(e, "M.stem.w", 48 * 96, &e->m_stem_w)); TRY(get_f32(e, "M.stem.b", 96, &e->m_stem_b));
+        TRY(get_f32(e, "M.stem.ln.g", 96, &e->m_stem_g)); TRY(get_f32(e, "M.stem.ln.b", 96, &e->m_stem_be));
+        for (int i = 0; i < 4; ++i) {
+            cs_engine::MStage& S = e->m_st[i];
+            const int C = dims[i];
+            S.C = C; S.n = depths[i];
+            for (int j = 0; j < S.n; ++j) {
+                cs_engine::MBlk& K = S.blk[j];
+                snprintf(n, sizeof n, "M.s%d.%d", i, j);
+                const std::string q(n);
+                TRY(get_f32(e, q + ".dw.w", 49 * C, &K.dw_w)); TRY(get_f32(e, q + ".dw.b", C, &K.dw_b));
+                TRY(get_f32(e, q + ".ln.g", C, &K.ln_g)); TRY(get_f32(e, q + ".ln.b", C, &K.ln_b));
+                TRY(get_f32(e, q + ".grn.g", 4 * C, &K.grn_g)); TRY(get_f32(e, q + ".grn.b", 4 * C, &K.grn_b));
+                TRY(get_conv(e, q + ".pw1", 3 * C, 4 * C, 4 * C, 1, 1, 1, 4 * C, (double)C * 4 * C, &K.pw1));   // split-precision: 3 x Cin
+                TRY(get_conv(e, q + ".pw2", 12 * C, C, C, 1, 1, 1, C, (double)C * 4 * C, &K.pw2));
+            }
+            if (i < 3) {
+                snprintf(n, sizeof n, "M.ds%d", i);
+                const std::string q(n);
+                TRY(get_f32(e, q + ".ln.g", C, &S.ds_g)); TRY(get_f32(e, q + ".ln.b", C, &S.ds_b));
+                TRY(get_conv(e, q, 12 * C, 2 * C, 2 * C, 1, 1, 1, 2 * C, (double)4 * C * 2 * C, &S.ds));
+            }
+        }
+        TRY(get_f32(e, "M.norm.g", 768, &e->m_norm_g)); TRY(get_f32(e, "M.norm.b", 768, &e->m_norm_b));
+        TRY(get_f32(e, "M.head.w", 328 * 768, &e->m_head_w)); TRY(get_f32(e, "M.head.b", 328, &e->m_head_b));
+    }
     // ---- F
     TRY(get_f32(e, "F.first.w", 64 * 27, &e->first_w)); TRY(get_f32(e, "F.first.b", 64, &e->first_b));
     TRY(get_conv(e, "F.down0", 64, 128, 128, 1, 3, 3, 128, 64.0 * 128 * 9, &e->f_down0));
@@ -887,6 +965,12 @@ extern "C" int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img
     hipStream_t st = (hipStream_t)stream;
     TRY(e->run(1, st, [&] { return launch_nchw_to_nhwc16(seg, e->seg16, B, 256, 4096, st); }, "nchw_to_nhwc16"));
     return run_G(e, B, e->seg16, img_out, st);
+}
+
+extern "C" int cs_motion_extract(cs_engine* e, int B, const float* img, float* out, void* stream)
+{
+    TRY(check(e, B));
+    return run_M(e, B, img, out, (hipStream_t)stream);
 }
 
 extern "C" int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W, void* stream)

@@ -1,0 +1,280 @@
+// Motion extractor M: the non-GEMM pieces of ConvNeXtV2-tiny for gfx950.
+// Reference: src/modules/convnextv2.py:15-144 (Block :34-46, stem / downsample :64-76, heads :98-106),
+// util.py:356-396 (GRN, LayerNorm).  The pointwise convs (pwconv1/2, the 2x2 stride-2 downsample convs after a
+// space-to-depth) run on conv_halo; everything here is bandwidth / latency bound and tiny (the whole network is
+// 11.6 GFLOP per frame against 2374 for the generator).
+//
+// Layout: residual stream x fp32 [N][H][W][C].  One wavefront owns one position and its lanes stride over the channels, so
+// LayerNorm is a wave reduction and every load is a contiguous 256-byte row.
+//
+// Precision: the key-points steer the generator's warps, and with fp16 GEMM operands M's outputs are only good to 1e-3
+// (41 dB on the generated frame).  M is 0.5 % of the frame's FLOPs, so its GEMMs run in split precision on the same fp16
+// MFMA kernel: an activation row of C' values is stored as the 3C' fp16 vector [hi | lo | hi] (hi = fp16(v), lo =
+// fp16(v - hi)) and the weights are packed as [W_hi | W_hi | W_lo] along the input-channel axis (pack._pack_M), so one
+// conv computes W_hi v_hi + W_hi v_lo + W_lo v_hi with fp32 accumulation (the dropped W_lo v_lo term is 2^-22 relative).
+#include "common.h"
+
+namespace {
+
+// store v as the split-precision triple [hi | lo | hi] at channel c of a row of C values (row stride 3C)
+__device__ __forceinline__ void store_split(half_t* row, int C, int c, float v)
+{
+    const half_t hi = (half_t)v;
+    row[c] = hi; row[C + c] = (half_t)(v - (float)hi); row[2 * C + c] = hi;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int MAXK = 12;   // channels per lane: 768 / 64
+
+// LayerNorm over C values spread as v[k] = channel lane + 64 k (biased variance, eps inside the sqrt: util.py:388-396)
+template <int K>
+__device__ __forceinline__ void wave_layernorm(float (&v)[K], int C, int lane, float eps)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (lane + 64 * k < C) s += v[k];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) if (lane + 64 * k < C) { const float d = v[k] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (v[k] - mean) * rstd;
+}
+
+// stem: Conv2d(3, 96, k=4, s=4) + LayerNorm(channels_first) (convnextv2.py:64-68). img fp32 NCHW -> x fp32 NHWC.
+// w: [48][96] with k = ci*16 + dy*4 + dx.
+__global__ void __launch_bounds__(256) m_stem_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ b,
+                                                     const float* __restrict__ g, const float* __restrict__ be, float* __restrict__ x,
+                                                     int N, int HI, int WI)
+{
+    const int lane = threadIdx.x & 63;
+    const int HO = HI / 4, WO = WI / 4;
+    const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= (long)N * HO * WO) return;
+    const int wo = pos % WO, ho = (pos / WO) % HO, n = pos / ((long)WO * HO);
+    float v[2] = {0.f, 0.f};
+    for (int k = 0; k < 48; ++k) {
+        const int ci = k >> 4, dy = (k >> 2) & 3, dx = k & 3;
+        const float a = img[(((long)n * 3 + ci) * HI + ho * 4 + dy) * WI + wo * 4 + dx];      // wave-uniform -> scalar load
+        v[0] = fmaf(a, w[k * 96 + lane], v[0]);
+        if (lane < 32) v[1] = fmaf(a, w[k * 96 + 64 + lane], v[1]);
+    }
+    v[0] += b[lane];
+    if (lane < 32) v[1] += b[64 + lane];
+    wave_layernorm<2>(v, 96, lane, 1e-6f);
+    float* o = x + pos * 96;
+    o[lane] = v[0] * g[lane] + be[lane];
+    if (lane < 32) o[64 + lane] = v[1] * g[64 + lane] + be[64 + lane];
+}
+
+// Block front half: depth-wise 7x7 conv (padding 3) + LayerNorm (convnextv2.py:36-38); x fp32 -> y split fp16 [N][H][W][3C].
+// wt: [49][C] (tap-major so lanes read consecutive channels).
+template <int K>
+__global__ void __launch_bounds__(256) m_dwln_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ b,
+                                                     const float* __restrict__ g, const float* __restrict__ be, half_t* __restrict__ y,
+                                                     int N, int H, int W, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= (long)N * H * W) return;
+    const int w0 = pos % W, h0 = (pos / W) % H, n = pos / ((long)W * H);
+    float v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (lane + 64 * k < C) ? b[lane + 64 * k] : 0.f;
+    for (int dy = 0; dy < 7; ++dy) {
+        const int h = h0 + dy - 3;
+        if ((unsigned)h >= (unsigned)H) continue;
+        for (int dx = 0; dx < 7; ++dx) {
+            const int ww = w0 + dx - 3;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            const float* xr = x + (((long)n * H + h) * W + ww) * C;
+            const float* wr = wt + (dy * 7 + dx) * C;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (lane + 64 * k < C) v[k] = fmaf(xr[lane + 64 * k], wr[lane + 64 * k], v[k]);
+        }
+    }
+    wave_layernorm<K>(v, C, lane, 1e-6f);
+    half_t* o = y + pos * 3 * C;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < C) store_split(o, C, lane + 64 * k, v[k] * g[lane + 64 * k] + be[lane + 64 * k]);
+}
+
+// Downsample front half: LayerNorm(channels_first) + space-to-depth for the 2x2 stride-2 conv (convnextv2.py:70-75):
+// x fp32 [N][H][W][C] -> y split fp16 [N][H/2][W/2][3 x 4C], inner index (dy*2+dx)*C + c.
+template <int K>
+__global__ void __launch_bounds__(256) m_ln_s2d_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
+                                                       half_t* __restrict__ y, int N, int H, int W, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= (long)N * H * W) return;
+    const int w0 = pos % W, h0 = (pos / W) % H, n = pos / ((long)W * H);
+    float v[K];
+    const float* xr = x + pos * C;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = (lane + 64 * k < C) ? xr[lane + 64 * k] : 0.f;
+    wave_layernorm<K>(v, C, lane, 1e-6f);
+    half_t* o = y + (((long)n * (H / 2) + (h0 >> 1)) * (W / 2) + (w0 >> 1)) * 12 * C;
+    const int sub = ((h0 & 1) * 2 + (w0 & 1)) * C;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < C) store_split(o, 4 * C, sub + lane + 64 * k, v[k] * g[lane + 64 * k] + be[lane + 64 * k]);
+}
+
+// GRN statistics (util.py:365-367): sumsq[n][c] = sum over the P positions of h[n][p][c]^2. Block = 64 channels x 4 position lanes.
+__global__ void __launch_bounds__(256) m_grn_sumsq_kernel(const float* __restrict__ h, float* __restrict__ sumsq, int P, int C)
+{
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
+    float s = 0.f;
+    for (int p = pl; p < P; p += 4) {
+        const float v = h[((long)n * P + p) * C + c];
+        s = fmaf(v, v, s);
+    }
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0) sumsq[(long)n * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// scale[n][c] = 1 + gamma[c] * Gx / (mean_c(Gx) + 1e-6), Gx = sqrt(sumsq)  (util.py:366-368: gamma*(x*Nx) + beta + x)
+__global__ void __launch_bounds__(256) m_grn_scale_kernel(const float* __restrict__ sumsq, const float* __restrict__ gamma,
+                                                          float* __restrict__ scale, int C)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += sqrtf(sumsq[(long)n * C + c]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float inv = 1.f / (red[0] / (float)C + 1e-6f);
+    for (int c = threadIdx.x; c < C; c += 256) scale[(long)n * C + c] = 1.f + gamma[c] * sqrtf(sumsq[(long)n * C + c]) * inv;
+}
+
+// out[pos] = split(h * scale[n][c] + beta[c]): fp32 [N][P][C] -> split fp16 [N][P][3C], 4 channels per thread
+__global__ void __launch_bounds__(256) m_grn_apply_kernel(const float* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ beta,
+                                                          half_t* __restrict__ out, long per_n, int C, long total4)
+{
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const long i = i4 * 4;
+    const int n = i / per_n, c = i % C;
+    const long pos = i / C;
+    const float4 q = *(const float4*)(h + i);
+    const float v[4] = {q.x, q.y, q.z, q.w};
+    h4_t hi, lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = v[r] * scale[(long)n * C + c + r] + beta[c + r];
+        hi[r] = (half_t)a; lo[r] = (half_t)(a - (float)hi[r]);
+    }
+    half_t* o = out + pos * 3 * C + c;
+    *(h4_t*)o = hi; *(h4_t*)(o + C) = lo; *(h4_t*)(o + 2 * C) = hi;
+}
+
+// Global average pool + final LayerNorm + the 7 linear heads (convnextv2.py:114-131). x fp32 [N][P][768] -> out fp32 [N][328]
+// in the order kp(63) scale(1) pitch(66) yaw(66) roll(66) t(3) exp(63). hw: [328][768].
+__global__ void __launch_bounds__(256) m_head_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
+                                                     const float* __restrict__ hw, const float* __restrict__ hb, float* __restrict__ out, int P)
+{
+    __shared__ float feat[768];
+    __shared__ float red[256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += x[((long)n * P + p) * 768 + t + 256 * k];
+        v[k] = s / (float)P;
+    }
+    red[t] = v[0] + v[1] + v[2];
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const float mean = red[0] / 768.f;
+    __syncthreads();
+    red[t] = (v[0] - mean) * (v[0] - mean) + (v[1] - mean) * (v[1] - mean) + (v[2] - mean) * (v[2] - mean);
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const float rstd = rsqrtf(red[0] / 768.f + 1e-6f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) feat[t + 256 * k] = (v[k] - mean) * rstd * g[t + 256 * k] + be[t + 256 * k];
+    __syncthreads();
+    for (int o = t; o < 328; o += 256) {
+        const float* wr = hw + (long)o * 768;
+        float s = hb[o];
+        for (int c = 0; c < 768; ++c) s = fmaf(feat[c], wr[c], s);
+        out[(long)n * 328 + o] = s;
+    }
+}
+
+}  // namespace
+
+#define M_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { cs_set_error(name ": %s", hipGetErrorString(e_)); return -1; } } while (0)
+
+int launch_m_stem(const float* img, const float* w, const float* b, const float* g, const float* be, float* x, int N, int HI, int WI, hipStream_t st)
+{
+    const long pos = (long)N * (HI / 4) * (WI / 4);
+    hipLaunchKernelGGL(m_stem_kernel, dim3((unsigned)((pos + 3) / 4)), dim3(256), 0, st, img, w, b, g, be, x, N, HI, WI);
+    M_LAUNCH_CHECK("m_stem");
+    return 0;
+}
+
+int launch_m_dwln(const float* x, const float* wt, const float* b, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st)
+{
+    const dim3 grid((unsigned)(((long)N * H * W + 3) / 4));
+    switch ((C + 63) / 64) {
+    case 2: hipLaunchKernelGGL(m_dwln_kernel<2>, grid, dim3(256), 0, st, x, wt, b, g, be, y, N, H, W, C); break;
+    case 3: hipLaunchKernelGGL(m_dwln_kernel<3>, grid, dim3(256), 0, st, x, wt, b, g, be, y, N, H, W, C); break;
+    case 6: hipLaunchKernelGGL(m_dwln_kernel<6>, grid, dim3(256), 0, st, x, wt, b, g, be, y, N, H, W, C); break;
+    case 12: hipLaunchKernelGGL(m_dwln_kernel<12>, grid, dim3(256), 0, st, x, wt, b, g, be, y, N, H, W, C); break;
+    default: cs_set_error("m_dwln: unsupported C=%d", C); return -1;
+    }
+    M_LAUNCH_CHECK("m_dwln");
+    return 0;
+}
+
+int launch_m_ln_s2d(const float* x, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st)
+{
+    const dim3 grid((unsigned)(((long)N * H * W + 3) / 4));
+    switch ((C + 63) / 64) {
+    case 2: hipLaunchKernelGGL(m_ln_s2d_kernel<2>, grid, dim3(256), 0, st, x, g, be, y, N, H, W, C); break;
+    case 3: hipLaunchKernelGGL(m_ln_s2d_kernel<3>, grid, dim3(256), 0, st, x, g, be, y, N, H, W, C); break;
+    case 6: hipLaunchKernelGGL(m_ln_s2d_kernel<6>, grid, dim3(256), 0, st, x, g, be, y, N, H, W, C); break;
+    default: cs_set_error("m_ln_s2d: unsupported C=%d", C); return -1;
+    }
+    M_LAUNCH_CHECK("m_ln_s2d");
+    return 0;
+}
+
+int launch_m_grn(const float* h, const float* gamma, const float* beta, float* sumsq, float* scale, half_t* out, int N, int P, int C, hipStream_t st)
+{
+    if (C % 64) { cs_set_error("m_grn: unsupported C=%d", C); return -1; }
+    hipLaunchKernelGGL(m_grn_sumsq_kernel, dim3(C / 64, N), dim3(256), 0, st, h, sumsq, P, C);
+    M_LAUNCH_CHECK("m_grn_sumsq");
+    hipLaunchKernelGGL(m_grn_scale_kernel, dim3(N), dim3(256), 0, st, sumsq, gamma, scale, C);
+    M_LAUNCH_CHECK("m_grn_scale");
+    const long total4 = (long)N * P * C / 4;
+    hipLaunchKernelGGL(m_grn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, h, scale, beta, out, (long)P * C, C, total4);
+    M_LAUNCH_CHECK("m_grn_apply");
+    return 0;
+}
+
+int launch_m_head(const float* x, const float* g, const float* be, const float* hw, const float* hb, float* out, int N, int P, hipStream_t st)
+{
+    hipLaunchKernelGGL(m_head_kernel, dim3(N), dim3(256), 0, st, x, g, be, hw, hb, out, P);
+    M_LAUNCH_CHECK("m_head");
+    return 0;
+}

@@ -136,6 +136,17 @@ class Engine:
         _lib.check(self.lib.cs_spade_decode(self.h, seg.shape[0], _ptr(seg), _ptr(img), self._stream()), "cs_spade_decode")
         return img
 
+    def motion_extract(self, img):
+        """MotionExtractor.forward (motion_extractor.py:33-35): Bx3x256x256 in [0,1] -> dict of raw head outputs."""
+        img = self._in(img, (3, 256, 256))
+        out = self._new(img.shape[0], 328)
+        _lib.check(self.lib.cs_motion_extract(self.h, img.shape[0], _ptr(img), _ptr(out), self._stream()), "cs_motion_extract")
+        res, o = {}, 0
+        for k, n in pack.M_HEADS:
+            res[k] = out[:, o:o + n].contiguous()
+            o += n
+        return res
+
     def pack_u8(self, img):
         img = self._in(img)
         B, _, H, W = img.shape

@@ -229,17 +229,64 @@ def _pack_G(out, sd):
     out["G.img.b"] = _f32(_pad(sd["conv_img.0.bias"], 16))
 
 
+M_DIMS, M_DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
+M_HEADS = (("kp", 63), ("scale", 1), ("pitch", 66), ("yaw", 66), ("roll", 66), ("t", 3), ("exp", 63))
+
+
+def split_precision_weight(w2d):
+    """[Cout][Cin] fp32 -> [Cout][3 Cin] = [W_hi | W_hi | W_lo] (fp16-representable values); pairs with activations stored
+    as [hi | lo | hi] (csrc/motion.hip) so that one fp16 MFMA conv yields W_hi v_hi + W_hi v_lo + W_lo v_hi."""
+    w2d = np.asarray(w2d, np.float32)
+    hi = w2d.astype(np.float16).astype(np.float32)
+    lo = (w2d - hi).astype(np.float16).astype(np.float32)
+    return np.concatenate([hi, hi, lo], axis=1)
+
+
+def _pack_M(out, sd):
+    """Motion extractor (convnextv2.py:48-108).  Linear layers become 1x1 convs; the 2x2 stride-2 downsample convs become
+    1x1 convs over a space-to-depth input whose channel index is (dy*2+dx)*C + c; depth-wise weights go tap-major."""
+    p = "detector."
+    w = sd[p + "downsample_layers.0.0.weight"]                                    # [96][3][4][4] -> [k = ci*16+dy*4+dx][96]
+    out["M.stem.w"] = _f32(w.reshape(96, 48).T)
+    out["M.stem.b"] = _f32(sd[p + "downsample_layers.0.0.bias"])
+    out["M.stem.ln.g"] = _f32(sd[p + "downsample_layers.0.1.weight"])
+    out["M.stem.ln.b"] = _f32(sd[p + "downsample_layers.0.1.bias"])
+    for i, (c, n) in enumerate(zip(M_DIMS, M_DEPTHS)):
+        for j in range(n):
+            q, o = f"{p}stages.{i}.{j}", f"M.s{i}.{j}"
+            out[o + ".dw.w"] = _f32(sd[q + ".dwconv.weight"].reshape(c, 49).T)
+            out[o + ".dw.b"] = _f32(sd[q + ".dwconv.bias"])
+            out[o + ".ln.g"] = _f32(sd[q + ".norm.weight"]); out[o + ".ln.b"] = _f32(sd[q + ".norm.bias"])
+            out[o + ".grn.g"] = _f32(sd[q + ".grn.gamma"].reshape(-1)); out[o + ".grn.b"] = _f32(sd[q + ".grn.beta"].reshape(-1))
+            out[o + ".pw1.w"] = pack_conv(split_precision_weight(sd[q + ".pwconv1.weight"])[:, :, None, None], 4 * c)
+            out[o + ".pw1.b"] = _f32(sd[q + ".pwconv1.bias"])
+            out[o + ".pw2.w"] = pack_conv(split_precision_weight(sd[q + ".pwconv2.weight"])[:, :, None, None], c)
+            out[o + ".pw2.b"] = _f32(sd[q + ".pwconv2.bias"])
+        if i < 3:
+            q, o = f"{p}downsample_layers.{i + 1}", f"M.ds{i}"
+            out[o + ".ln.g"] = _f32(sd[q + ".0.weight"]); out[o + ".ln.b"] = _f32(sd[q + ".0.bias"])
+            w = sd[q + ".1.weight"]                                               # [2C][C][2][2] -> [2C][(dy,dx,c)]
+            out[o + ".w"] = pack_conv(split_precision_weight(np.transpose(w, (0, 2, 3, 1)).reshape(2 * c, 4 * c))[:, :, None, None], 2 * c)
+            out[o + ".b"] = _f32(sd[q + ".1.bias"])
+    out["M.norm.g"] = _f32(sd[p + "norm.weight"]); out["M.norm.b"] = _f32(sd[p + "norm.bias"])
+    out["M.head.w"] = _f32(np.concatenate([sd[f"{p}fc_{k}.weight"] for k, _ in M_HEADS], 0))
+    out["M.head.b"] = _f32(np.concatenate([sd[f"{p}fc_{k}.bias"] for k, _ in M_HEADS], 0))
+    assert out["M.head.w"].shape == (328, 768)
+
+
 def _np_sd(sd):
     return {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
 
 
 def build_blobs(state_dicts: dict) -> dict:
     """``state_dicts``: {'appearance_feature_extractor', 'warping_module', 'spade_generator', 'transfer',
-    'refine'} -> {blob name: contiguous ndarray}; values may be torch tensors or numpy arrays."""
+    'refine'[, 'motion_extractor']} -> {blob name: contiguous ndarray}; values may be torch tensors or numpy arrays."""
     out: dict = {}
     _pack_F(out, _np_sd(state_dicts["appearance_feature_extractor"]))
     _pack_W(out, _np_sd(state_dicts["warping_module"]))
     _pack_T(out, _np_sd(state_dicts["transfer"]))
     _pack_R(out, _np_sd(state_dicts["refine"]))
     _pack_G(out, _np_sd(state_dicts["spade_generator"]))
+    if "motion_extractor" in state_dicts:                      # optional (SURVEY section 8f row N1)
+        _pack_M(out, _np_sd(state_dicts["motion_extractor"]))
     return out

@@ -184,9 +184,51 @@ _BUILDERS = {
 }
 
 
+def _motion_extractor(seed):
+    """MotionExtractor(backbone='convnextv2_tiny', num_kp=21) state-dict (motion_extractor.py:18-35, convnextv2.py:48-108).
+    Magnitudes are chosen so that the 18 residual blocks keep O(1) activations and every head output is non-degenerate."""
+    b = _Builder(seed, "M")
+    dims, depths = (96, 192, 384, 768), (3, 3, 9, 3)
+
+    def ln(name, c):
+        b.sd[f"{name}.weight"] = b._r(f"{name}.weight").uniform(0.8, 1.2, size=(c,)).astype(np.float32)
+        b.sd[f"{name}.bias"] = b._r(f"{name}.bias").uniform(-0.1, 0.1, size=(c,)).astype(np.float32)
+
+    b.conv("detector.downsample_layers.0.0", dims[0], 3, 4, 4)
+    ln("detector.downsample_layers.0.1", dims[0])
+    for i in range(3):
+        ln(f"detector.downsample_layers.{i + 1}.0", dims[i])
+        b.conv(f"detector.downsample_layers.{i + 1}.1", dims[i + 1], dims[i], 2, 2)
+    for i, (c, n) in enumerate(zip(dims, depths)):
+        for j in range(n):
+            q = f"detector.stages.{i}.{j}"
+            fan = 49
+            bound = np.sqrt(3.0 / fan)
+            b.sd[f"{q}.dwconv.weight"] = b._r(f"{q}.dwconv.weight").uniform(-bound, bound, size=(c, 1, 7, 7)).astype(np.float32)
+            b.sd[f"{q}.dwconv.bias"] = b._r(f"{q}.dwconv.bias").uniform(-0.1, 0.1, size=(c,)).astype(np.float32)
+            ln(f"{q}.norm", c)
+            b.linear(f"{q}.pwconv1", 4 * c, c)
+            b.sd[f"{q}.grn.gamma"] = (0.5 * b._r(f"{q}.grn.gamma").standard_normal((1, 1, 1, 4 * c))).astype(np.float32)
+            b.sd[f"{q}.grn.beta"] = (0.1 * b._r(f"{q}.grn.beta").standard_normal((1, 1, 1, 4 * c))).astype(np.float32)
+            b.linear(f"{q}.pwconv2", c, 4 * c, gain=0.5)
+    ln("detector.norm", dims[-1])
+    b.linear("detector.fc_kp", 3 * NUM_KP, dims[-1], gain=0.3)
+    b.linear("detector.fc_scale", 1, dims[-1], gain=0.1)
+    b.sd["detector.fc_scale.bias"] = np.array([1.1], np.float32)
+    for k in ("pitch", "yaw", "roll"):
+        b.linear(f"detector.fc_{k}", 66, dims[-1], gain=2.0)
+    b.linear("detector.fc_t", 3, dims[-1], gain=0.1)
+    b.linear("detector.fc_exp", 3 * NUM_KP, dims[-1], gain=0.05)
+    return b.sd
+
+
+_BUILDERS["motion_extractor"] = _motion_extractor
+
+
 def make_state_dicts(seed: int = 0, modules=MODULES) -> dict:
     """Return ``{module_name: OrderedDict[str, np.ndarray]}`` laid out like the reference's
-    ``combined_weights.pth`` (``src/can_swap_e2e.py:87-100``; the motion extractor is outside the hot path)."""
+    ``combined_weights.pth`` (``src/can_swap_e2e.py:87-100``).  The motion extractor is built on
+    request: ``modules=MODULES + ("motion_extractor",)``."""
     return {m: _BUILDERS[m](seed) for m in modules}
 
 
@@ -225,6 +267,20 @@ def make_frame_inputs(n_frames: int, seed: int = 1000, size: int = 256) -> dict:
         x_can[i] = scale * kp
         x_t[i] = scale * (kp @ _rot(*ang) + exp) + t
     return {"img": img, "x_t": x_t, "x_can": x_can}
+
+
+def make_smooth_images(n: int, seed: int = 2000, size: int = 256) -> np.ndarray:
+    """(n,3,size,size) fp32 in [0,1]: low-frequency blobs + a little noise (inputs that make the motion extractor's pooled
+    features differ between frames, which white noise does not)."""
+    r = _rng(seed, "smooth")
+    coarse = r.uniform(0, 1, size=(n, 3, 8, 8)).astype(np.float32)
+    t = np.linspace(0, 7, size, dtype=np.float32)
+    i0 = np.clip(np.floor(t).astype(np.int64), 0, 6)
+    f = t - i0
+    rows = coarse[:, :, i0, :] * (1 - f)[None, None, :, None] + coarse[:, :, i0 + 1, :] * f[None, None, :, None]
+    img = rows[:, :, :, i0] * (1 - f) + rows[:, :, :, i0 + 1] * f
+    img = img + 0.05 * r.standard_normal(img.shape).astype(np.float32)
+    return np.clip(img, 0, 1).astype(np.float32)
 
 
 def make_identity(seed: int = 7, n: int = 1) -> np.ndarray:

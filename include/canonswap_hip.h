@@ -54,6 +54,10 @@ int cs_warp_forward(cs_engine* e, int B, const float* f, const float* kp_driving
                     float* occ_out, float* deformation_out, float* seg_out, void* stream);
 /* SPADEDecoder.forward (spade_generator.py:41-59): seg Bx256x64x64 -> img Bx3x512x512 in (0,1) */
 int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img_out, void* stream);
+/* MotionExtractor.forward (motion_extractor.py:33-35 -> convnextv2.py:110-144), as called by can_swapper.get_kp_info
+ * (can_swap_e2e.py:174-199): img Bx3x256x256 fp32 in [0,1] -> out Bx328 fp32, the raw head outputs concatenated in the order
+ * kp(63) scale(1) pitch(66) yaw(66) roll(66) t(3) exp(63).  Needs the "M.*" blobs. */
+int cs_motion_extract(cs_engine* e, int B, const float* img, float* out, void* stream);
 /* can_swapper.parse_output on device (can_swap_e2e.py:314-322): Bx3xHxW fp32 -> BxHxWx3 u8 (truncation) */
 int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W, void* stream);
 /* The whole per-frame loop body (can_swap_pipeline_e2e.py:242-263) for B frames without leaving the device:

@@ -429,6 +429,65 @@ def transform_keypoint(kp_info: dict) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# M  motion extractor: ConvNeXtV2-tiny + 7 linear heads
+# (src/modules/convnextv2.py:15-144, motion_extractor.py:18-35)
+# ------------------------------------------------------------------------------------------------
+M_DIMS, M_DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
+M_HEADS = (("kp", 63), ("scale", 1), ("pitch", 66), ("yaw", 66), ("roll", 66), ("t", 3), ("exp", 63))   # convnextv2.py:98-106
+
+
+def _ln_last(x, sd, p, eps=1e-6):
+    """LayerNorm over the last (channel) axis, biased variance (util.py:388-396 both data formats)."""
+    u = x.mean(-1, keepdim=True)
+    v = ((x - u) ** 2).mean(-1, keepdim=True)
+    return (x - u) / torch.sqrt(v + eps) * sd[p + ".weight"] + sd[p + ".bias"]
+
+
+def convnext_block(x, sd, p):
+    """convnextv2.py:34-46 on a channels-last tensor x (N,H,W,C): x + pw2(grn(gelu(pw1(ln(dw7x7(x))))))."""
+    c = x.shape[-1]
+    y = F.conv2d(x.permute(0, 3, 1, 2), sd[p + ".dwconv.weight"], sd[p + ".dwconv.bias"], padding=3, groups=c).permute(0, 2, 3, 1)
+    y = _ln_last(y, sd, p + ".norm")
+    y = F.gelu(y @ sd[p + ".pwconv1.weight"].t() + sd[p + ".pwconv1.bias"])            # exact (erf) GELU
+    gx = torch.sqrt((y * y).sum(dim=(1, 2), keepdim=True))                              # util.py:365-368
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    y = sd[p + ".grn.gamma"] * (y * nx) + sd[p + ".grn.beta"] + y
+    return x + (y @ sd[p + ".pwconv2.weight"].t() + sd[p + ".pwconv2.bias"])
+
+
+def motion_features(sd, img):
+    """forward_features (convnextv2.py:110-114); img (N,3,H,W) in [0,1] -> (N,768)."""
+    p = "detector."
+    x = F.conv2d(img, sd[p + "downsample_layers.0.0.weight"], sd[p + "downsample_layers.0.0.bias"], stride=4).permute(0, 2, 3, 1)
+    x = _ln_last(x, sd, p + "downsample_layers.0.1")
+    for i in range(4):
+        if i > 0:
+            x = _ln_last(x, sd, p + f"downsample_layers.{i}.0")
+            x = F.conv2d(x.permute(0, 3, 1, 2), sd[p + f"downsample_layers.{i}.1.weight"], sd[p + f"downsample_layers.{i}.1.bias"],
+                         stride=2).permute(0, 2, 3, 1)
+        for j in range(M_DEPTHS[i]):
+            x = convnext_block(x, sd, p + f"stages.{i}.{j}")
+    return _ln_last(x.mean(dim=(1, 2)), sd, p + "norm")
+
+
+def motion_extractor(sd, img):
+    """MotionExtractor.forward (motion_extractor.py:33-35): dict of raw head outputs."""
+    f = motion_features(sd, img)
+    return {k: f @ sd[f"detector.fc_{k}.weight"].t() + sd[f"detector.fc_{k}.bias"] for k, _ in M_HEADS}
+
+
+def get_kp_info(sd, img):
+    """can_swap_e2e.py:174-199 with flag_refine_info=True."""
+    info = motion_extractor(sd, img)
+    bs = img.shape[0]
+    for k in ("pitch", "yaw", "roll"):
+        info[k] = headpose_pred_to_degree(info[k])[:, None]
+    info["kp"] = info["kp"].reshape(bs, -1, 3)
+    info["exp"] = info["exp"].reshape(bs, -1, 3)
+    return info
+
+
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)

@@ -18,6 +18,10 @@ SHAPES = [
     ("G conv 512->512 3x3 @64 B16", 16, 512, 512, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->1024 3x3 @64 B16", 16, 128, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->512 3x3 @128 B16", 16, 128, 512, 1, 128, 128, (1, 3, 3), 0, -2, (0, 0)),
+    ("G gb 128->1024 3x3 @64 B16 (128x128)", 16, 128, 1024, 1, 64, 64, (1, 3, 3), 0, 10, (0, 0)),
+    ("G gb 128->512 3x3 @128 B16 (128x128)", 16, 128, 512, 1, 128, 128, (1, 3, 3), 0, 10, (0, 0)),
+    ("G gb 128->128 3x3 @256 B16 (128x128)", 16, 128, 128, 1, 256, 256, (1, 3, 3), 0, 10, (0, 0)),
+    ("G gb 128->128 3x3 @256 B16 (128x64)", 16, 128, 128, 1, 256, 256, (1, 3, 3), 0, 11, (0, 0)),
     ("G shared 256->384 3x3 @256 B4", 4, 256, 384, 1, 256, 256, (1, 3, 3), 0, -2, (0, 0)),
     ("W maskp 144->160 7x7x1 B8", 8, 144, 160, 16, 64, 64, (7, 7, 1), 0, 18, (2, 8)),
     ("W tail 144->160 3x3x3 B8", 8, 144, 160, 16, 64, 64, (3, 3, 3), 0, 18, (8, 8)),

@@ -71,6 +71,31 @@ def unit_vectors():
                 exp=exp.numpy(), t=t.numpy(), scale=scale.numpy(), x_transformed=xt.numpy())
 
 
+def motion_case(n=3, img_seed=2000, size=256):
+    """Reference MotionExtractor (motion_extractor.py:18-35) + per-stage statistics of its ConvNeXtV2 trunk."""
+    sys.path.insert(0, REF)
+    import yaml
+    from src.modules.motion_extractor import MotionExtractor
+    cfg = yaml.safe_load(open(os.path.join(REF, "src/config/models.yaml")))["model_params"]
+    m = MotionExtractor(**cfg["motion_extractor_params"]).eval()
+    m.load_state_dict(synth.to_torch(synth.make_state_dicts(0, modules=("motion_extractor",)))["motion_extractor"], strict=True)
+    img = torch.from_numpy(synth.make_smooth_images(n, seed=img_seed, size=size))
+    out = {"n": n, "img_seed": img_seed, "size": size}
+    with torch.no_grad():
+        for k, v in m(img).items():
+            out[k] = v.numpy().astype(np.float32)
+        x, d = img, m.detector
+        for i in range(4):
+            x = d.downsample_layers[i](x)
+            x = d.stages[i](x)
+            v = x.numpy().reshape(-1)
+            idx = sample_idx(f"m_stage{i}", v.size)
+            out[f"stage{i}_idx"] = idx
+            out[f"stage{i}_val"] = v[idx].astype(np.float32)
+            out[f"stage{i}_stats"] = np.array([v.mean(), v.std()], np.float64)
+    return out
+
+
 def main():
     torch.manual_seed(0)
     sds = synth.to_torch(synth.make_state_dicts(0))
@@ -80,6 +105,7 @@ def main():
     np.savez_compressed(os.path.join(gold, "frame_128_b2.npz"), **case(mods, 128, 2, 2000, 7, debug=True))
     np.savez_compressed(os.path.join(gold, "frame_256_b1.npz"), **case(mods, 256, 1, 1000, 7, debug=False))
     np.savez_compressed(os.path.join(gold, "unit_vectors.npz"), **unit_vectors())
+    np.savez_compressed(os.path.join(gold, "motion_b3.npz"), **motion_case())
     for f in sorted(os.listdir(gold)):
         print(f, os.path.getsize(os.path.join(gold, f)))
 
