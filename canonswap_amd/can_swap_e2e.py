@@ -163,6 +163,11 @@ class can_swapper(object):
     def swap_frames(self, I_s, x_t, x_can, source_id, debug=False, want_u8=False):
         return self.engine.swap_frames(I_s, x_t, x_can, source_id, want_f32=True, want_u8=want_u8, debug=debug)
 
+    # ---- addition: the per-frame body of can_swap_pipeline_v2i.py:311-312 (warp_decode of one swapped canonical volume
+    # under the driving key-points of B frames)
+    def animate_frames(self, f_swap_can, x_swap, x_t, want_u8=False):
+        return self.engine.animate_frames(f_swap_can, x_swap, x_t, want_f32=True, want_u8=want_u8)
+
 
 def headpose_pred_to_degree(pred):
     """src/utils/camera.py:14-28."""

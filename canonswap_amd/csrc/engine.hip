@@ -1016,6 +1016,30 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
     return 0;
 }
 
+// v2i per-frame body (can_swap_pipeline_v2i.py:311-312: warp_decode of ONE swapped canonical feature volume under per-frame
+// driving key-points). nf / ns = 1 (shared by all B frames) or B.
+extern "C" int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, const float* kp_source, int ns, const float* kp_driving,
+                                 float* out_f32, uint8_t* out_u8, void* stream)
+{
+    TRY(check(e, B));
+    if ((nf != 1 && nf != B) || (ns != 1 && ns != B)) { cs_set_error("cs_animate_frames: nf / ns must be 1 or B"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    TRY(to_hwdc(e, nf, f, e->vs[0], nullptr, st));
+    for (int b = nf; b < B; ++b) TRY(copy_dd(e->vs[0] + (size_t)b * VOL, e->vs[0], (size_t)VOL * 4, st));
+    const float* ks = kp_source;
+    if (ns == 1 && B > 1) {
+        for (int b = 0; b < B; ++b) TRY(copy_dd(e->kpbuf + (size_t)b * 63, kp_source, 63 * 4, st));
+        ks = e->kpbuf;
+    }
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, ks, nullptr, st));
+    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
+    float* dst = out_f32 ? out_f32 : e->img_a;
+    TRY(run_G(e, B, e->seg16, dst, st));
+    if (out_u8) TRY(e->run(1, st, [&] { return launch_pack_u8(dst, out_u8, B, 3, 512, 512, st); }, "pack_u8"));
+    return 0;
+}
+
 extern "C" int cs_profile_begin(cs_engine* e)
 {
     if (!e) { cs_set_error("null engine"); return -1; }

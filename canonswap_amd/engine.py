@@ -174,6 +174,22 @@ class Engine:
             res.update(rec_can=rec, swap_can=swp)
         return res
 
+    def animate_frames(self, f, kp_source, kp_driving, want_f32=True, want_u8=False, out_f32=None, out_u8=None):
+        """Per-frame body of can_swap_pipeline_v2i.py:311-312 for B driving frames: one (or B) feature volume(s) f and source
+        key-point set(s), B driving key-point sets -> Bx3x512x512."""
+        kp_driving = self._in(kp_driving, (21, 3))
+        B = kp_driving.shape[0]
+        f = self._in(f, (32, 16, 64, 64)); kp_source = self._in(kp_source, (21, 3))
+        if f.shape[0] not in (1, B) or kp_source.shape[0] not in (1, B):
+            raise ValueError("f and kp_source must hold 1 or B entries")
+        if want_f32 and out_f32 is None:
+            out_f32 = self._new(B, 3, 512, 512)
+        if want_u8 and out_u8 is None:
+            out_u8 = self._new(B, 512, 512, 3, dtype=torch.uint8)
+        _lib.check(self.lib.cs_animate_frames(self.h, B, _ptr(f), f.shape[0], _ptr(kp_source), kp_source.shape[0], _ptr(kp_driving),
+                                              _ptr(out_f32), _ptr(out_u8), self._stream()), "cs_animate_frames")
+        return {"out": out_f32, "out_u8": out_u8}
+
     # ---------------------------------------------------------------- measurement
     def profile_begin(self):
         _lib.check(self.lib.cs_profile_begin(self.h), "cs_profile_begin")

@@ -65,6 +65,12 @@ int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W
  * (debug decodes of lines 248 / 257, Bx3x512x512) may each be NULL. */
 int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
                    float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream);
+/* The per-frame body of the video-to-image pipeline (can_swap_pipeline_v2i.py:311-312):
+ * warp_decode(f, kp_source, kp_driving) -> 3x512x512 for B driving frames.  f: nf x 32x16x64x64 feature volumes and
+ * kp_source: ns x 21x3, with nf / ns = 1 (one swapped canonical volume / key-point set shared by all frames) or B;
+ * kp_driving Bx21x3.  out_f32 (Bx3x512x512) and out_u8 (Bx512x512x3) may each be NULL. */
+int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, const float* kp_source, int ns, const float* kp_driving,
+                      float* out_f32, uint8_t* out_u8, void* stream);
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream */
 int cs_profile_begin(cs_engine* e);

@@ -178,3 +178,22 @@ def test_missing_weights_are_an_error():
     with pytest.raises(RuntimeError, match="cs_finalize_weights has not been called"):
         e.extract_feature_3d(torch.zeros(1, 3, 256, 256).cuda())
     e.close()
+
+
+def test_animate_frames_v2i(swapper, case, state_dicts):
+    """one feature volume + one source key-point set, B driving key-point sets
+    (can_swap_pipeline_v2i.py:311-312) against the oracle's warp_decode and against the stage API."""
+    from oracle import canonswap_ref as O
+    args, _, ref = case
+    f = ref["f_ref"][:1]
+    ks, kd = args["x_can"][:1], args["x_t"]
+    with torch.no_grad():
+        seg = O.warping_forward(state_dicts["warping_module"], f.expand(2, -1, -1, -1, -1), kp_driving=kd, kp_source=ks.expand(2, -1, -1))["out"]
+        want = O.spade_decoder(state_dicts["spade_generator"], seg)
+    got = swapper.animate_frames(f.cuda(), ks.cuda(), kd.cuda(), want_u8=True)
+    assert got["out"].shape == (2, 3, 512, 512) and got["out_u8"].shape == (2, 512, 512, 3)
+    assert O.psnr(got["out"].cpu(), want) >= PSNR_GATE
+    stage = swapper.warp_decode(f.expand(2, -1, -1, -1, -1).contiguous().cuda(), ks.expand(2, -1, -1).contiguous().cuda(), kd.cuda())["out"]
+    assert O.psnr(got["out"].cpu(), stage.cpu()) > 60.0
+    with pytest.raises(ValueError):
+        swapper.animate_frames(ref["f_ref"][:2].repeat(2, 1, 1, 1, 1)[:3].cuda(), ks.cuda(), kd.cuda())
