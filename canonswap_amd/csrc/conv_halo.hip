@@ -47,7 +47,11 @@ template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3,
 template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
-__global__ void __launch_bounds__(256, (WCH == 4 ? 2 : 1)) conv_halo_kernel(const ConvParams p)
+// Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
+// unrolled 128x128 tiles (<= 168 VGPRs, no scratch) -- for short-K convs a third workgroup hides the prologue / epilogue
+// of the other two (gamma/beta convs K = 9 x 128: +15 % over the 128x256 tile, tools/ab_conv.sh); the dynamic-shape
+// variants would spill at that budget and stay unconstrained.
+__global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 && !SK && ST != 0) ? 3 : 1))) conv_halo_kernel(const ConvParams p)
 {
     using SS = StaticShape<ST>;
     static_assert(ST == 0 || !SK, "static shapes are not combined with split-K");

@@ -531,6 +531,9 @@ int spade_gb(cs_engine* e, const cs_engine::GB& gb, int C, const half_t* actv, i
     c.p.stats = stats;
     c.p.act0 = act; c.p.slope0 = 0.2f;
     c.p.out0 = nhwc(out, S, S, C);
+    // K = 9 x 128 only: three resident 128x128 workgroups per CU beat two 128x256 ones (CANONSWAP_GB256=1 restores the latter)
+    static const bool wide = getenv("CANONSWAP_GB256") != nullptr;
+    if (!wide && gb.conv.Cout_pad % 128 == 0) c.hcfg = CFG_H_128x128;
     return go(e, c, st);
 }
 

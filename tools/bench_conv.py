@@ -18,6 +18,10 @@ SHAPES = [
     ("G conv 512->512 3x3 @64 B16", 16, 512, 512, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->1024 3x3 @64 B16", 16, 128, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->512 3x3 @128 B16", 16, 128, 512, 1, 128, 128, (1, 3, 3), 0, -2, (0, 0)),
+    ("T fused 512->1024 3x3 @64 B16 (128x128)", 16, 512, 1024, 1, 64, 64, (1, 3, 3), 0, 10, (0, 0)),
+    ("G conv 512->512 3x3 @64 B16 (128x128)", 16, 512, 512, 1, 64, 64, (1, 3, 3), 0, 10, (0, 0)),
+    ("G conv 256->256 3x3 @128 B16", 16, 256, 256, 1, 128, 128, (1, 3, 3), 0, -2, (0, 0)),
+    ("G conv 256->256 3x3 @128 B16 (128x128)", 16, 256, 256, 1, 128, 128, (1, 3, 3), 0, 10, (0, 0)),
     ("G gb 128->1024 3x3 @64 B16 (128x128)", 16, 128, 1024, 1, 64, 64, (1, 3, 3), 0, 10, (0, 0)),
     ("G gb 128->512 3x3 @128 B16 (128x128)", 16, 128, 512, 1, 128, 128, (1, 3, 3), 0, 10, (0, 0)),
     ("G gb 128->128 3x3 @256 B16 (128x128)", 16, 128, 128, 1, 256, 256, (1, 3, 3), 0, 10, (0, 0)),
