@@ -684,6 +684,8 @@ int from_hwdc(cs_engine* e, int B, const float* in, float* out, hipStream_t st)
 extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
 {
     if (!out || max_batch < 1) { cs_set_error("cs_create: bad arguments"); return -1; }
+    // the kernels keep per-tensor element offsets in 32 bits; the largest activation (B x 256 x 256 x 384) reaches 2^31 at B = 85
+    if (max_batch > 64) { cs_set_error("cs_create: max_batch %d exceeds 64 (32-bit element offsets inside one tensor)", max_batch); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) {
         cs_set_error("cs_create: HIP device %d not available (%d devices visible)", device_id, ndev);

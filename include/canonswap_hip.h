@@ -23,7 +23,7 @@ extern "C" {
 typedef struct cs_engine cs_engine;
 
 /* ---- life cycle (replaces can_swapper.__init__ / load_cpk, src/can_swap_e2e.py:44-100) */
-int cs_create(int device_id, int max_batch, cs_engine** out);
+int cs_create(int device_id, int max_batch, cs_engine** out);   /* 1 <= max_batch <= 64; workspace ~0.35 GB per frame of batch */
 void cs_destroy(cs_engine* e);
 const char* cs_last_error(void);
 int cs_abi_version(void);

@@ -197,3 +197,9 @@ def test_animate_frames_v2i(swapper, case, state_dicts):
     assert O.psnr(got["out"].cpu(), stage.cpu()) > 60.0
     with pytest.raises(ValueError):
         swapper.animate_frames(ref["f_ref"][:2].repeat(2, 1, 1, 1, 1)[:3].cuda(), ks.cuda(), kd.cuda())
+
+
+def test_max_batch_guard():
+    from canonswap_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="max_batch"):
+        Engine(0, max_batch=65)

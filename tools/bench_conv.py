@@ -14,6 +14,14 @@ import hip_ops as ops  # noqa: E402
 DEV = "cuda:0"
 # name, N, Cin, Cout_pad, D, H, W, k, up_shift, halo cfg, tile, real_flop_factor
 SHAPES = [
+    ("Tscan B2", 2, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B4", 4, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B8", 8, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B12", 12, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B16", 16, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B24", 24, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B32", 32, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
+    ("Tscan B64", 64, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("T fused 512->1024 3x3 @64 B16", 16, 512, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G conv 512->512 3x3 @64 B16", 16, 512, 512, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
     ("G gb 128->1024 3x3 @64 B16", 16, 128, 1024, 1, 64, 64, (1, 3, 3), 0, -2, (0, 0)),
