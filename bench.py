@@ -117,6 +117,15 @@ def main():
         cpu = {"value": round(n_cpu / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"{n_cpu} frames (1 warm-up), batch 1, fp32 PyTorch-CPU restatement of the same path (oracle/)"}
 
+    traffic, traffic_src = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    if rank == 0 and os.path.exists(tpath):      # PMC counters cannot be read from inside this process: committed rocprofv3 passes
+        import json as _json
+        t = _json.load(open(tpath))
+        if int(t.get("batch", -1)) == B:
+            traffic = t["fetch_bytes_per_conv_launch_x2"] + t["write_bytes_per_conv_launch_raw"]
+            traffic_src = "profiles/hbm_traffic.json: " + t["source"]
+
     if rank == 0:
         frames = K * B * world
         fps = frames / dt
@@ -132,7 +141,8 @@ def main():
                        "frames_per_step_per_gpu": B, "frames_total": frames, "parallelism": f"frame-shard x{world}",
                        "accumulate": "fp32", "debug_decodes": False},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per conv launch",
+                         "traffic_source": traffic_src,
                          "kernel": "conv_halo + conv_igemm (every convolution launch)", "launches_per_step": prof["conv_launches"] // K,
                          "avg_launch_us": round(prof["conv_ms"] * 1e3 / prof["conv_launches"], 2),
                          "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * B) / 1e9, 1),
