@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libcanonswap_hip.so")
 ABI_SYMBOLS = [
     "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity",
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_refine", "cs_warp_forward", "cs_spade_decode",
-    "cs_pack_u8", "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_op_conv", "cs_op_grid_sample3d",
+    "cs_pack_u8", "cs_unpack_u8", "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_op_conv", "cs_op_grid_sample3d",
     "cs_op_chan_stats", "cs_op_chan_stats_partial_floats",
 ]
 
@@ -83,6 +83,7 @@ def load():
     lib.cs_warp_forward.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.cs_spade_decode.argtypes = [vp, ci, vp, vp, vp]
     lib.cs_pack_u8.argtypes = [vp, ci, vp, vp, ci, ci, vp]
+    lib.cs_unpack_u8.argtypes = [vp, ci, vp, vp, ci, ci, vp]
     lib.cs_motion_extract.argtypes = [vp, ci, vp, vp, vp]
     lib.cs_animate_frames.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp]
     lib.cs_swap_frames.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]

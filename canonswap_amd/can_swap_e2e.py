@@ -111,6 +111,8 @@ class can_swapper(object):
     def prepare_source(self, img: np.ndarray) -> torch.Tensor:
         if img.shape[0] != 256 or img.shape[1] != 256:
             raise ValueError("prepare_source expects the 256x256 crop produced by the cropper")
+        if img.dtype == np.uint8:                 # upload 1 byte per sample and convert on the device (same arithmetic)
+            return self.engine.unpack_u8(img[np.newaxis] if img.ndim == 3 else img)
         if img.ndim == 3:
             x = img[np.newaxis].astype(np.float32) / 255.
         elif img.ndim == 4:
@@ -127,6 +129,8 @@ class can_swapper(object):
             _imgs = imgs
         else:
             raise ValueError(f'imgs type error: {type(imgs)}')
+        if _imgs.dtype == np.uint8 and _imgs.ndim == 5 and _imgs.shape[-1] == 1:
+            return self.engine.unpack_u8(_imgs[..., 0]).unsqueeze(1)          # T x 1 x 3 x H x W
         y = np.clip(_imgs.astype(np.float32) / 255., 0, 1)
         return torch.from_numpy(y).permute(0, 4, 3, 1, 2).to(self.device)
 

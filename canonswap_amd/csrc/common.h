@@ -113,6 +113,8 @@ int launch_t_modulate(const float* wraw, const float* style, half_t* packed, int
 int launch_pack_u8(const float* img, uint8_t* out, int N, int C, int H, int W, hipStream_t st);
 int launch_lrelu16(const half_t* in, half_t* out, long n, float slope, hipStream_t st);
 
+int launch_unpack_u8(const uint8_t* in, float* out, int N, int C, int H, int W, hipStream_t st);
+
 // ---- motion extractor pieces (motion.hip)
 int launch_m_stem(const float* img, const float* w, const float* b, const float* g, const float* be, float* x, int N, int HI, int WI, hipStream_t st);
 int launch_m_dwln(const float* x, const float* wt, const float* b, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st);

@@ -985,6 +985,13 @@ extern "C" int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, i
     return e->run(1, st, [&] { return launch_pack_u8(img, out, B, 3, H, W, st); }, "pack_u8");
 }
 
+extern "C" int cs_unpack_u8(cs_engine* e, int B, const uint8_t* img, float* out, int H, int W, void* stream)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_unpack_u8(img, out, B, 3, H, W, st); }, "unpack_u8");
+}
+
 extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
                               float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream)
 {

@@ -705,6 +705,23 @@ int launch_pack_u8(const float* img, uint8_t* out, int N, int C, int H, int W, h
     return 0;
 }
 
+// prepare_source / prepare_videos on device (can_swap_e2e.py:126-163): NHWC u8 -> NCHW fp32 / 255 (already inside [0,1])
+__global__ void __launch_bounds__(256) unpack_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int N, int C, int H, int W)
+{
+    const long total = (long)N * H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / ((long)H * W), p = i % ((long)H * W);
+    for (int c = 0; c < C; ++c) out[(n * C + c) * (long)H * W + p] = (float)in[i * C + c] / 255.f;
+}
+
+int launch_unpack_u8(const uint8_t* in, float* out, int N, int C, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(unpack_u8_kernel, dim3(cdiv((long)N * H * W, 256)), dim3(256), 0, st, in, out, N, C, H, W);
+    LAUNCH_CHECK("unpack_u8");
+    return 0;
+}
+
 __global__ void __launch_bounds__(256) lrelu16_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, long n8, float slope)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

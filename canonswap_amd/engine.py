@@ -154,6 +154,17 @@ class Engine:
         _lib.check(self.lib.cs_pack_u8(self.h, B, _ptr(img), _ptr(out), H, W, self._stream()), "cs_pack_u8")
         return out
 
+    def unpack_u8(self, img_u8):
+        """BxHxWx3 uint8 (host or device) -> Bx3xHxW fp32 in [0,1] on the device (prepare_source / prepare_videos arithmetic)."""
+        t = torch.as_tensor(img_u8)
+        if t.dtype != torch.uint8 or t.ndim != 4 or t.shape[3] != 3:
+            raise ValueError("expected a BxHxWx3 uint8 array")
+        t = t.to(self.device).contiguous()
+        B, H, W, _ = t.shape
+        out = self._new(B, 3, H, W)
+        _lib.check(self.lib.cs_unpack_u8(self.h, B, _ptr(t), _ptr(out), H, W, self._stream()), "cs_unpack_u8")
+        return out
+
     def swap_frames(self, img, x_t, x_can, source_id=None, want_f32=True, want_u8=False, debug=False,
                     out_f32=None, out_u8=None):
         """Whole loop body of can_swap_pipeline_e2e.py:242-263 for B frames, on device."""

@@ -60,6 +60,8 @@ int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img_out, void*
 int cs_motion_extract(cs_engine* e, int B, const float* img, float* out, void* stream);
 /* can_swapper.parse_output on device (can_swap_e2e.py:314-322): Bx3xHxW fp32 -> BxHxWx3 u8 (truncation) */
 int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W, void* stream);
+/* can_swapper.prepare_source / prepare_videos on device (can_swap_e2e.py:126-163): BxHxWx3 u8 -> Bx3xHxW fp32 = u8 / 255 */
+int cs_unpack_u8(cs_engine* e, int B, const uint8_t* img, float* out, int H, int W, void* stream);
 /* The whole per-frame loop body (can_swap_pipeline_e2e.py:242-263) for B frames without leaving the device:
  * img Bx3x256x256, x_t / x_can Bx21x3.  out_f32 (Bx3x512x512), out_u8 (Bx512x512x3), rec_can, swap_can
  * (debug decodes of lines 248 / 257, Bx3x512x512) may each be NULL. */

@@ -203,3 +203,20 @@ def test_max_batch_guard():
     from canonswap_amd.engine import Engine
     with pytest.raises(RuntimeError, match="max_batch"):
         Engine(0, max_batch=65)
+
+
+def test_prepare_on_device_bit_exact(swapper):
+    """A1 (can_swap_e2e.py:126-163): uint8 crops are uploaded as bytes and divided by 255 on the device - same fp32 values."""
+    r = np.random.Generator(np.random.PCG64(5))
+    img = r.integers(0, 256, size=(256, 256, 3), dtype=np.uint8)
+    want = np.clip(img[np.newaxis].astype(np.float32) / 255., 0, 1).transpose(0, 3, 1, 2)
+    got = swapper.prepare_source(img)
+    assert got.shape == (1, 3, 256, 256) and got.dtype == torch.float32 and got.is_cuda
+    assert np.array_equal(got.cpu().numpy(), want)
+    vid = [r.integers(0, 256, size=(256, 256, 3), dtype=np.uint8) for _ in range(3)]
+    v = swapper.prepare_videos(vid)
+    assert v.shape == (3, 1, 3, 256, 256)
+    wantv = np.clip(np.array(vid)[..., np.newaxis].astype(np.float32) / 255., 0, 1).transpose(0, 4, 3, 1, 2)
+    assert np.array_equal(v.cpu().numpy(), wantv)
+    f = swapper.prepare_source(img.astype(np.float32))          # float input keeps the host path
+    assert np.array_equal(f.cpu().numpy(), want)
