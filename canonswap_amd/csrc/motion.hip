@@ -75,37 +75,61 @@ __global__ void __launch_bounds__(256) m_stem_kernel(const float* __restrict__ i
 }
 
 // Block front half: depth-wise 7x7 conv (padding 3) + LayerNorm (convnextv2.py:36-38); x fp32 -> y split fp16 [N][H][W][3C].
-// wt: [49][C] (tap-major so lanes read consecutive channels).
+// wt: [49][C] (tap-major so lanes read consecutive channels).  One wavefront owns a run of DWP consecutive positions of a row:
+// every input element of the 7 x (DWP+6) window is loaded once and scattered into the outputs it feeds (4x fewer loads than
+// a window per position), the 7 weights of the current kernel row sit in registers.
+constexpr int DWP = 8;
 template <int K>
 __global__ void __launch_bounds__(256) m_dwln_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ b,
                                                      const float* __restrict__ g, const float* __restrict__ be, half_t* __restrict__ y,
                                                      int N, int H, int W, int C)
 {
     const int lane = threadIdx.x & 63;
-    const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pos >= (long)N * H * W) return;
-    const int w0 = pos % W, h0 = (pos / W) % H, n = pos / ((long)W * H);
-    float v[K];
+    const int runs_per_row = W / DWP;                                   // W is 64, 32, 16 or 8
+    const long run = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (run >= (long)N * H * runs_per_row) return;
+    const int w0 = (int)(run % runs_per_row) * DWP, h0 = (int)((run / runs_per_row) % H), n = (int)(run / ((long)runs_per_row * H));
+    float acc[DWP][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = (lane + 64 * k < C) ? b[lane + 64 * k] : 0.f;
+    for (int p = 0; p < DWP; ++p)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[p][k] = (lane + 64 * k < C) ? b[lane + 64 * k] : 0.f;
     for (int dy = 0; dy < 7; ++dy) {
         const int h = h0 + dy - 3;
         if ((unsigned)h >= (unsigned)H) continue;
-        for (int dx = 0; dx < 7; ++dx) {
-            const int ww = w0 + dx - 3;
-            if ((unsigned)ww >= (unsigned)W) continue;
-            const float* xr = x + (((long)n * H + h) * W + ww) * C;
-            const float* wr = wt + (dy * 7 + dx) * C;
+        float wk[7][K];
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (lane + 64 * k < C) v[k] = fmaf(xr[lane + 64 * k], wr[lane + 64 * k], v[k]);
+        for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+            for (int k = 0; k < K; ++k) wk[dx][k] = (lane + 64 * k < C) ? wt[(dy * 7 + dx) * C + lane + 64 * k] : 0.f;
+        const float* xrow = x + ((long)n * H + h) * W * C;
+#pragma unroll
+        for (int j = 0; j < DWP + 6; ++j) {                             // input column w0 - 3 + j feeds output p with tap dx = j - p
+            const int ww = w0 - 3 + j;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            float xv[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) xv[k] = (lane + 64 * k < C) ? xrow[(long)ww * C + lane + 64 * k] : 0.f;
+#pragma unroll
+            for (int p = 0; p < DWP; ++p) {
+                const int dx = j - p;
+                if (dx < 0 || dx > 6) continue;
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[p][k] = fmaf(xv[k], wk[dx][k], acc[p][k]);
+            }
         }
     }
-    wave_layernorm<K>(v, C, lane, 1e-6f);
-    half_t* o = y + pos * 3 * C;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (lane + 64 * k < C) store_split(o, C, lane + 64 * k, v[k] * g[lane + 64 * k] + be[lane + 64 * k]);
+    for (int p = 0; p < DWP; ++p) {
+        float v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = acc[p][k];
+        wave_layernorm<K>(v, C, lane, 1e-6f);
+        half_t* o = y + ((((long)n * H + h0) * W) + w0 + p) * 3 * C;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (lane + 64 * k < C) store_split(o, C, lane + 64 * k, v[k] * g[lane + 64 * k] + be[lane + 64 * k]);
+    }
 }
 
 // Downsample front half: LayerNorm(channels_first) + space-to-depth for the 2x2 stride-2 conv (convnextv2.py:70-75):
@@ -234,7 +258,8 @@ int launch_m_stem(const float* img, const float* w, const float* b, const float*
 
 int launch_m_dwln(const float* x, const float* wt, const float* b, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st)
 {
-    const dim3 grid((unsigned)(((long)N * H * W + 3) / 4));
+    if (W % DWP) { cs_set_error("m_dwln: width %d is not a multiple of %d", W, DWP); return -1; }
+    const dim3 grid((unsigned)(((long)N * H * (W / DWP) + 3) / 4));
     switch ((C + 63) / 64) {
     case 2: hipLaunchKernelGGL(m_dwln_kernel<2>, grid, dim3(256), 0, st, x, wt, b, g, be, y, N, H, W, C); break;
     case 3: hipLaunchKernelGGL(m_dwln_kernel<3>, grid, dim3(256), 0, st, x, wt, b, g, be, y, N, H, W, C); break;
