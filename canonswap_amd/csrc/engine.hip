@@ -252,7 +252,9 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     const int Cout_pad = p.Cout_pad;
     if (mode == MODE_PIXSHUF) return CFG_H_256x16;
     // 128 positions x 256 channels (64 channels per wave) only exists as the fully unrolled 3x3 / 16x8-tile kernel
-    if (Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0) return CFG_H_128x256;
+    // 2 resident 128x256 workgroups win only for the T blend convs (N = 1024, 4 channel blocks per tile: +4.7 %); everywhere
+    // else 3 resident 128x128 workgroups are 4-14 % faster (G 3x3 convs, fc, F down-blocks) - measured per layer with tools/cmp_layers.py
+    if (mode == MODE_TBLEND && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0) return CFG_H_128x256;
     if (Cout_pad % 128 == 0) return CFG_H_128x128;
     if (Cout_pad % 64 == 0) return CFG_H_128x64;
     if (Cout_pad % 32 == 0) return CFG_H_128x32;
@@ -531,10 +533,7 @@ int spade_gb(cs_engine* e, const cs_engine::GB& gb, int C, const half_t* actv, i
     c.p.stats = stats;
     c.p.act0 = act; c.p.slope0 = 0.2f;
     c.p.out0 = nhwc(out, S, S, C);
-    // K = 9 x 128 only: three resident 128x128 workgroups per CU beat two 128x256 ones (CANONSWAP_GB256=1 restores the latter)
-    static const bool wide = getenv("CANONSWAP_GB256") != nullptr;
-    if (!wide && gb.conv.Cout_pad % 128 == 0) c.hcfg = CFG_H_128x128;
-    return go(e, c, st);
+    return go(e, c, st);   // 128x128 tiles, three resident workgroups per CU (pick_halo_cfg)
 }
 
 int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
