@@ -392,6 +392,11 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         ConvCall c = mk(e->w_dec[i], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, S, S, 1);
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_l[lv - 1], FD, S, S, lw[lv - 1]);
+        if (i == 4) {   // 128 -> 32 channels at full resolution: the 256-position x 32-channel tile (4x4x16 positions) issues twice the
+            c.hcfg = CFG_H_256x32;                       // MFMAs per weight fragment of the 128x32 one: 0.47 -> 0.27 ms at B = 16
+            TRY(go(e, c, st, 4, 4));
+            continue;
+        }
         TRY(go(e, c, st));
     }
     ConvCall t = mk(e->w_tail, e->dm_l[0], dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // util.py:261-263
