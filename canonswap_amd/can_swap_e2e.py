@@ -107,6 +107,30 @@ class can_swapper(object):
             kp_info["exp"] = kp_info["exp"].reshape(bs, -1, 3)
         return kp_info
 
+    def get_pose_dct(self, kp_info: dict) -> dict:                                       # (:201-207)
+        return {k: headpose_pred_to_degree(kp_info[k]).item() for k in ("pitch", "yaw", "roll")}
+
+    def get_fs_and_kp_info(self, source_prepared, driving_first_frame):                  # (:209-226)
+        s_info = self.get_kp_info(source_prepared, flag_refine_info=True)
+        s_rot = get_rotation_matrix(s_info["pitch"], s_info["yaw"], s_info["roll"])
+        d_info = self.get_kp_info(driving_first_frame, flag_refine_info=True)
+        d_rot = get_rotation_matrix(d_info["pitch"], d_info["yaw"], d_info["roll"])
+        return s_info, s_rot, self.extract_feature_3d(source_prepared), d_info, d_rot
+
+    # ---- landmark ratios of the driving crops (:324-348; host-side numpy on 2-D landmarks, as in the reference)
+    def calc_ratio(self, lmk_lst):
+        return [eye_close_ratio(l[None]) for l in lmk_lst], [lip_close_ratio(l[None]) for l in lmk_lst]
+
+    def calc_combined_eye_ratio(self, c_d_eyes_i, source_lmk):
+        c_s = torch.from_numpy(eye_close_ratio(source_lmk[None])).float().to(self.device)
+        c_d = torch.tensor([[float(c_d_eyes_i[0][0])]], device=self.device)
+        return torch.cat([c_s, c_d], dim=1)
+
+    def calc_combined_lip_ratio(self, c_d_lip_i, source_lmk):
+        c_s = torch.from_numpy(lip_close_ratio(source_lmk[None])).float().to(self.device)
+        c_d = torch.tensor([[float(np.asarray(c_d_lip_i[0]).reshape(-1)[0])]], device=self.device)
+        return torch.cat([c_s, c_d], dim=1)
+
     # ---- data preparation (:126-163)
     def prepare_source(self, img: np.ndarray) -> torch.Tensor:
         if img.shape[0] != 256 or img.shape[1] != 256:
@@ -171,6 +195,23 @@ class can_swapper(object):
     # under the driving key-points of B frames)
     def animate_frames(self, f_swap_can, x_swap, x_t, want_u8=False):
         return self.engine.animate_frames(f_swap_can, x_swap, x_t, want_f32=True, want_u8=want_u8)
+
+
+def _distance_ratio(lmk, a, b, c, d, eps=1e-6):
+    """|lmk[a]-lmk[b]| / (|lmk[c]-lmk[d]| + eps) per row of lmk (B x n_points x 2) -> (B, 1)  (retargeting_utils.py:9-11)."""
+    num = np.linalg.norm(lmk[:, a] - lmk[:, b], axis=1, keepdims=True)
+    den = np.linalg.norm(lmk[:, c] - lmk[:, d], axis=1, keepdims=True)
+    return num / (den + eps)
+
+
+def eye_close_ratio(lmk):
+    """Left / right eye opening over eye width, (B, 2)  (retargeting_utils.py:14-20 without a target ratio)."""
+    return np.concatenate([_distance_ratio(lmk, 6, 18, 0, 12), _distance_ratio(lmk, 30, 42, 24, 36)], axis=1)
+
+
+def lip_close_ratio(lmk):
+    """Lip opening over mouth width, (B, 1)  (retargeting_utils.py:23-24)."""
+    return _distance_ratio(lmk, 90, 102, 48, 66)
 
 
 def headpose_pred_to_degree(pred):

@@ -99,3 +99,21 @@ def test_missing_motion_weights(state_dicts):
     sw = can_swapper(None, state_dicts=state_dicts, max_batch=1)
     with pytest.raises(RuntimeError):
         sw.get_kp_info(torch.zeros(1, 3, 256, 256, device="cuda"))
+
+
+def test_pose_and_source_helpers(swapper_m, sds_m, imgs):
+    """get_pose_dct / get_fs_and_kp_info / calc_ratio (can_swap_e2e.py:201-226, 324-331) on the engine."""
+    from oracle import canonswap_ref as O
+    raw = swapper_m.get_kp_info(imgs[:1].cuda(), flag_refine_info=False)
+    pose = swapper_m.get_pose_dct(raw)
+    with torch.no_grad():
+        ref = O.motion_extractor(sds_m["motion_extractor"], imgs[:1])
+    for k in ("pitch", "yaw", "roll"):
+        assert abs(pose[k] - O.headpose_pred_to_degree(ref[k]).item()) <= 0.01
+    s_info, s_rot, f_s, d_info, d_rot = swapper_m.get_fs_and_kp_info(imgs[:1].cuda(), imgs[1:2].cuda())
+    assert f_s.shape == (1, 32, 16, 64, 64) and s_rot.shape == (1, 3, 3) and d_info["kp"].shape == (1, 21, 3)
+    lmk = [np.random.default_rng(0).uniform(0, 256, size=(106, 2)).astype(np.float32) for _ in range(2)]
+    eyes, lips = swapper_m.calc_ratio(lmk)
+    assert len(eyes) == 2 and eyes[0].shape == (1, 2) and lips[0].shape == (1, 1)
+    assert swapper_m.calc_combined_eye_ratio(eyes[0], lmk[1]).shape == (1, 3)
+    assert swapper_m.calc_combined_lip_ratio(lips[0], lmk[1]).shape == (1, 2)

@@ -87,3 +87,12 @@ def test_keypoint_helpers_match_golden(golden):
     pyr = torch.from_numpy(g["pyr"])
     assert np.abs(get_rotation_matrix(pyr[:, 0], pyr[:, 1], pyr[:, 2]).numpy() - g["rot"]).max() < 1e-6
     assert np.abs(headpose_pred_to_degree(torch.from_numpy(g["bins"])).numpy() - g["deg"]).max() < 1e-4
+
+
+def test_landmark_ratios_match_reference_vectors(golden):
+    """calc_ratio's helpers (can_swap_e2e.py:324-348) against values computed by the reference's retargeting_utils."""
+    from canonswap_amd import can_swap_e2e as H
+    g = golden("unit_vectors.npz")
+    assert np.allclose(H.eye_close_ratio(g["lmk"]), g["eye_ratio"], rtol=0, atol=1e-6)
+    assert np.allclose(H.lip_close_ratio(g["lmk"]), g["lip_ratio"], rtol=0, atol=1e-6)
+    assert H.eye_close_ratio(g["lmk"][:1]).shape == (1, 2) and H.lip_close_ratio(g["lmk"][:1]).shape == (1, 1)

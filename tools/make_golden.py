@@ -67,7 +67,11 @@ def unit_vectors():
     xt = kp @ rot + exp
     xt = xt * scale[..., None]
     xt[:, :, 0:2] += t[:, None, 0:2]
-    return dict(pyr=pyr.numpy(), rot=rot.numpy(), bins=bins.numpy(), deg=deg.numpy(), kp=kp.numpy(),
+    from src.utils.retargeting_utils import calc_eye_close_ratio, calc_lip_close_ratio
+    lmk = r.uniform(0, 256, size=(4, 106, 2)).astype(np.float32)
+    eye, lip = calc_eye_close_ratio(lmk), calc_lip_close_ratio(lmk)
+    return dict(lmk=lmk, eye_ratio=eye, lip_ratio=lip,
+                pyr=pyr.numpy(), rot=rot.numpy(), bins=bins.numpy(), deg=deg.numpy(), kp=kp.numpy(),
                 exp=exp.numpy(), t=t.numpy(), scale=scale.numpy(), x_transformed=xt.numpy())
 
 
