@@ -220,3 +220,18 @@ def test_prepare_on_device_bit_exact(swapper):
     assert np.array_equal(v.cpu().numpy(), wantv)
     f = swapper.prepare_source(img.astype(np.float32))          # float input keeps the host path
     assert np.array_equal(f.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("frame_seed,id_seed,smooth", [(4321, 11, False), (777, 3, True), (90210, 29, True)])
+def test_psnr_other_inputs(swapper, state_dicts, frame_seed, id_seed, smooth):
+    """The 50 dB gate on further frames: other key-points / identities, and low-frequency (image-like) inputs."""
+    from canonswap_amd import synth
+    from oracle import canonswap_ref as O
+    inp = synth.make_frame_inputs(1, seed=frame_seed, size=256)
+    img = torch.from_numpy(synth.make_smooth_images(1, seed=frame_seed) if smooth else inp["img"])
+    x_t, x_can = torch.from_numpy(inp["x_t"]), torch.from_numpy(inp["x_can"])
+    idv = torch.from_numpy(synth.make_identity(id_seed))
+    with torch.no_grad():
+        ref = O.swap_frame(state_dicts, img, x_t, x_can, idv)
+    out = swapper.swap_frames(img.cuda(), x_t.cuda(), x_can.cuda(), idv.cuda())["out"]
+    assert O.psnr(out.cpu(), ref["out"]) >= PSNR_GATE
