@@ -68,6 +68,12 @@ class Engine:
             raise ValueError(f"batch {t.shape[0]} outside [1, {self.max_batch}]")
         return t
 
+    @staticmethod
+    def _same_batch(*ts):
+        n = {int(t.shape[0]) for t in ts if t is not None}
+        if len(n) != 1:
+            raise ValueError(f"inputs disagree on the batch size: {sorted(n)}")
+
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
@@ -95,6 +101,7 @@ class Engine:
 
     def warp(self, f, kp_source, kp_driving):
         f = self._in(f, (32, 16, 64, 64)); ks = self._in(kp_source, (21, 3)); kd = self._in(kp_driving, (21, 3))
+        self._same_batch(f, ks, kd)
         B = f.shape[0]
         out, occ = self._new(B, 32, 16, 64, 64), self._new(B, 1, 64, 64)
         _lib.check(self.lib.cs_warp(self.h, B, _ptr(f), _ptr(ks), _ptr(kd), _ptr(out), _ptr(occ), self._stream()), "cs_warp")
@@ -104,6 +111,7 @@ class Engine:
         f = self._in(f, (32, 16, 64, 64))
         B = f.shape[0]
         occ = None if occ is None else self._in(occ, (1, 64, 64))
+        self._same_batch(f, occ)
         seg = self._new(B, 256, 64, 64)
         _lib.check(self.lib.cs_warp_out(self.h, B, _ptr(f), _ptr(occ), _ptr(seg), self._stream()), "cs_warp_out")
         return seg
@@ -124,6 +132,7 @@ class Engine:
 
     def warp_forward(self, f, kp_driving, kp_source):
         f = self._in(f, (32, 16, 64, 64)); kd = self._in(kp_driving, (21, 3)); ks = self._in(kp_source, (21, 3))
+        self._same_batch(f, ks, kd)
         B = f.shape[0]
         occ, deform, seg = self._new(B, 1, 64, 64), self._new(B, 16, 64, 64, 3), self._new(B, 256, 64, 64)
         _lib.check(self.lib.cs_warp_forward(self.h, B, _ptr(f), _ptr(kd), _ptr(ks), _ptr(occ), _ptr(deform), _ptr(seg),
@@ -171,6 +180,7 @@ class Engine:
         if source_id is not None:
             self.ensure_identity(source_id)
         img = self._in(img, (3, 256, 256)); x_t = self._in(x_t, (21, 3)); x_can = self._in(x_can, (21, 3))
+        self._same_batch(img, x_t, x_can)
         B = img.shape[0]
         if want_f32 and out_f32 is None:
             out_f32 = self._new(B, 3, 512, 512)

@@ -235,3 +235,26 @@ def test_psnr_other_inputs(swapper, state_dicts, frame_seed, id_seed, smooth):
         ref = O.swap_frame(state_dicts, img, x_t, x_can, idv)
     out = swapper.swap_frames(img.cuda(), x_t.cuda(), x_can.cuda(), idv.cuda())["out"]
     assert O.psnr(out.cpu(), ref["out"]) >= PSNR_GATE
+
+
+def test_empty_ragged_and_mistyped_inputs(swapper, case):
+    """Empty batches, mismatched batch sizes and wrong ranks are refused before any launch; integer images are converted."""
+    args, idv, _ = case
+    img, x_t, x_can = args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda()
+    with pytest.raises(ValueError):
+        swapper.swap_frames(img[:0], x_t[:0], x_can[:0], idv.cuda())                 # empty batch
+    with pytest.raises(ValueError):
+        swapper.swap_frames(img, x_t[:1].reshape(1, 63), x_can, idv.cuda())          # key-points not Bx21x3
+    with pytest.raises(ValueError):
+        swapper.swap_frames(img, x_t[:1], x_can, idv.cuda())                         # ragged: 2 frames, 1 key-point set
+    with pytest.raises(ValueError):
+        swapper.warp_decode(swapper.extract_feature_3d(img), x_can[:1], x_t)         # ragged stage call
+    with pytest.raises(ValueError):
+        swapper.warping_module.warp(torch.zeros(2, 32, 16, 64, 32).cuda(), x_t, x_can)  # truncated volume
+    with pytest.raises(TypeError):
+        swapper.extract_feature_3d(args["img"].numpy())                              # not a tensor
+    with pytest.raises(ValueError):
+        swapper.engine.set_identity(torch.randn(2, 512))                             # two different identities in one slot
+    a = swapper.extract_feature_3d(img)
+    b = swapper.extract_feature_3d(img.double())                                     # other float types are cast, same result
+    assert torch.equal(a, b)
