@@ -38,6 +38,7 @@ __device__ __forceinline__ void wait_vmcnt_le()
 //   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
 //   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
 //   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
+//   ST 10 / 11: 1x2x3 and 1x1x3, tile 16x8 (the row-phase convs of mlp_shared on the up-sampled seg, engine.hip run_G)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
@@ -45,6 +46,8 @@ template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3,
 template <> struct StaticShape<4> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 3; };
 template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
+template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 3, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 1, KW = 3, LW = 4, LH = 3, LD = 0; };
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 // Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
@@ -434,6 +437,10 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
     // candidate static shape for this launch
     if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
     const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? (p.lgTW == 1 ? 6 : 4) : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
+    if (cfg == CFG_H_128x128 && mode == MODE_STD && ck == 64 && p.KD == 1 && p.KW == 3 && (p.KH == 2 || p.KH == 1)) {
+        if (p.KH == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 10>(p, st);
+        return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 11>(p, st);
+    }
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
     if (cfg == CFG && mode == MODE) {                                                                    \
         if (ck == 64) return launch_halo_cfg<64, WPX, WCH, WVP, WVC, MODE, SK, ST2D>(p, st);            \

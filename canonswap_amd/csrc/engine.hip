@@ -68,6 +68,8 @@ struct cs_engine {
     struct S3 { ConvL c1, c2; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];
     struct RB2 { ConvL c1, c2; Affine pre; } r_rb2[3];
     ConvL g_fc, g_sh64, g_sh128, g_sh256, g_img;
+    ConvL g_sh128p[2], g_sh256p[4];        // mlp_shared convs of the up blocks per output row phase on the source grid
+    int g_shp_ph[2][4] = {};               // their top padding
     struct GB { ConvL conv; const float *bg, *bb; };
     struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs; bool learned; int fin, fmid, fout; } g_blk[8];
 
@@ -548,12 +550,27 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     ConvCall s64 = mk(e->g_sh64, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
     s64.p.act0 = ACT_RELU; s64.p.out0 = nhwc(e->g_a64, 64, 64, 1536);
     TRY(go(e, s64, st));
-    ConvCall s128 = mk(e->g_sh128, seg, nhwc(nullptr, 64, 64, 256), B, 1, 128, 128, 1);
-    s128.p.act0 = ACT_RELU; s128.p.out0 = nhwc(e->g_a128, 128, 128, 384);
-    TRY(go(e, s128, st));
-    ConvCall s256 = mk(e->g_sh256, seg, nhwc(nullptr, 64, 64, 256), B, 1, 256, 256, 2);
-    s256.p.act0 = ACT_RELU; s256.p.out0 = nhwc(e->g_a256, 256, 256, 384);
-    TRY(go(e, s256, st));
+    // mlp_shared of the up blocks reads seg nearest-resized to 128 / 256 (util.py:297-298): run per output row phase on the 64x64
+    // source grid, column phases as output-channel blocks (pack.upsampled_conv_phases): 6/9 and 18/36 of the taps, same result
+    static const bool direct = getenv("CANONSWAP_SHARED_DIRECT") != nullptr;     // A/B knob: 3x3 convs on the up-sampled grid
+    for (int lv = 0; lv < 2; ++lv) {
+        const int sc = lv ? 4 : 2, S = 64 * sc;
+        half_t* dst = lv ? e->g_a256 : e->g_a128;
+        if (direct) {
+            ConvCall c = mk(lv ? e->g_sh256 : e->g_sh128, seg, nhwc(nullptr, 64, 64, 256), B, 1, S, S, lv ? 2 : 1);
+            c.p.act0 = ACT_RELU; c.p.out0 = nhwc(dst, S, S, 384);
+            TRY(go(e, c, st));
+            continue;
+        }
+        for (int a = 0; a < sc; ++a) {
+            ConvCall c = mk(lv ? e->g_sh256p[a] : e->g_sh128p[a], seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
+            c.p.PH = e->g_shp_ph[lv][a];
+            c.p.act0 = ACT_RELU;
+            // output pixel (sc*i + a, sc*j + b), channel c  <-  source position (i, j), channel b*384 + c
+            c.p.out0 = td(dst + (long)a * S * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+            TRY(go(e, c, st));
+        }
+    }
 
     int cx = 0;
     for (int b = 0; b < 6; ++b) {   // SPADEResnetBlock 512->512 @64x64 (util.py:329-344)
@@ -855,6 +872,16 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     TRY(get_conv(e, "G.shared64", 256, 1536, 1536, 1, 3, 3, 1536, 256.0 * 1536 * 9, &e->g_sh64));
     TRY(get_conv(e, "G.shared128", 256, 384, 384, 1, 3, 3, 384, 256.0 * 384 * 9, &e->g_sh128));
     TRY(get_conv(e, "G.shared256", 256, 384, 384, 1, 3, 3, 384, 256.0 * 384 * 9, &e->g_sh256));
+    for (int lv = 0; lv < 2; ++lv) {
+        const int sc = lv ? 4 : 2;
+        for (int a = 0; a < sc; ++a) {
+            const int kh = (a == 0 || a == sc - 1) ? 2 : 1;           // rows {-1,0}, {0}, ..., {0,+1}
+            e->g_shp_ph[lv][a] = a == 0 ? 1 : 0;
+            snprintf(n, sizeof n, "G.shared%d.p%d", lv ? 256 : 128, a);
+            // algorithmic MACs stay those of the 3x3 conv on the up-sampled grid: sc*sc output pixels per source position, split over sc launches
+            TRY(get_conv(e, n, 256, sc * 384, sc * 384, 1, kh, 3, sc * 384, 256.0 * 384 * 9 * sc, lv ? &e->g_sh256p[a] : &e->g_sh128p[a]));
+        }
+    }
     auto get_gb = [&](const std::string& b, int C, cs_engine::GB* gb) -> int {
         const int pad = ((2 * C + 127) / 128) * 128;
         TRY(get_conv(e, b, 128, pad, C, 1, 3, 3, 0, 128.0 * 2 * C * 9, &gb->conv));

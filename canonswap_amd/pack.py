@@ -201,6 +201,27 @@ def _pack_gb(out, n, sd, p):
     out[n + ".bb"] = _f32(sd[p + ".mlp_beta.bias"])
 
 
+def upsampled_conv_phases(w, s):
+    """3x3 'same' conv applied to a nearest-x`s` up-sampled map (SPADE resizes seg to x's size, util.py:297-298) as `s` convs on
+    the SOURCE grid, one per output row phase a (y = s*i + a): row taps collapse to the 1-2 source rows they read, the column
+    phases b become output-channel blocks with a 3-wide column kernel (zero where a phase does not use a source column).
+    Exact: taps that land on the same source pixel add their weights; zero padding of the up-sampled map is zero padding of
+    the source grid.  Returns [(KH, PH, w_a [s*Co][Ci][KH][3])] for a = 0..s-1; output channel = b*Co + co."""
+    w = np.asarray(w, np.float64)
+    co, ci = w.shape[:2]
+    off = lambda ph, d: (ph + d - 1) // s            # source offset (-1, 0, +1) read by tap d of output phase ph
+    res = []
+    for a in range(s):
+        rows = sorted({off(a, dy) for dy in range(3)})
+        wa = np.zeros((s * co, ci, len(rows), 3), np.float64)
+        for b in range(s):
+            for dy in range(3):
+                for dx in range(3):
+                    wa[b * co:(b + 1) * co, :, rows.index(off(a, dy)), off(b, dx) + 1] += w[:, :, dy, dx]
+        res.append((len(rows), -rows[0], wa))
+    return res
+
+
 def _pack_G(out, sd):
     out["G.fc.w"] = pack_conv(sd["fc.weight"], 512)
     out["G.fc.b"] = _f32(sd["fc.bias"])
@@ -213,6 +234,11 @@ def _pack_G(out, sd):
         w = np.concatenate([sd[q + ".mlp_shared.0.weight"] for q in lst], 0)
         out[n + ".w"] = pack_conv(w, w.shape[0])
         out[n + ".b"] = _f32(np.concatenate([sd[q + ".mlp_shared.0.bias"] for q in lst]))
+        s_up = {"G.shared128": 2, "G.shared256": 4}.get(n)
+        if s_up:      # the same convs per output row phase on the 64x64 source grid (2.25x / 4x fewer taps, engine.hip run_G)
+            for a, (kh, ph, wa) in enumerate(upsampled_conv_phases(w, s_up)):
+                out[f"{n}.p{a}.w"] = pack_conv(wa, wa.shape[0])
+                out[f"{n}.p{a}.b"] = _f32(np.tile(out[n + ".b"], s_up))
     blocks = [(f"G.m{b}", f"G_middle_{b}") for b in range(6)] + [("G.up0", "up_0"), ("G.up1", "up_1")]
     for n, p in blocks:
         for k in ("0", "1"):

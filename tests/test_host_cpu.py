@@ -96,3 +96,19 @@ def test_landmark_ratios_match_reference_vectors(golden):
     assert np.allclose(H.eye_close_ratio(g["lmk"]), g["eye_ratio"], rtol=0, atol=1e-6)
     assert np.allclose(H.lip_close_ratio(g["lmk"]), g["lip_ratio"], rtol=0, atol=1e-6)
     assert H.eye_close_ratio(g["lmk"][:1]).shape == (1, 2) and H.lip_close_ratio(g["lmk"][:1]).shape == (1, 1)
+
+
+@pytest.mark.parametrize("s", [2, 4])
+def test_upsampled_conv_phase_decomposition(s):
+    """pack.upsampled_conv_phases: a 3x3 conv on a nearest-up-sampled map == per-row-phase convs on the source grid."""
+    r = np.random.Generator(np.random.PCG64(s))
+    w, x = r.standard_normal((5, 3, 3, 3)), r.standard_normal((2, 3, 8, 8))
+    ref = F.conv2d(F.interpolate(torch.from_numpy(x), scale_factor=s, mode="nearest"), torch.from_numpy(w), padding=1).numpy()
+    out = np.zeros_like(ref)
+    phases = pack.upsampled_conv_phases(w, s)
+    assert [kh for kh, _, _ in phases] == ([2, 2] if s == 2 else [2, 1, 1, 2])
+    for a, (kh, ph, wa) in enumerate(phases):
+        y = F.conv2d(F.pad(torch.from_numpy(x), (1, 1, ph, kh - 1 - ph)), torch.from_numpy(wa)).numpy()
+        for b in range(s):
+            out[:, :, a::s, b::s] = y[:, b * 5:(b + 1) * 5]
+    assert np.abs(out - ref).max() < 1e-12
