@@ -38,6 +38,7 @@ __device__ __forceinline__ void wait_vmcnt_le()
 //   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
 //   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
 //   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
+//   ST 12 / 13: 3x2x2, tiles 4x4x16 and 8x8x2 (the hourglass up-blocks per output phase on the source grid)
 //   ST 10 / 11: 1x2x3 and 1x1x3, tile 16x8 (the row-phase convs of mlp_shared on the up-sampled seg, engine.hip run_G)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
@@ -46,6 +47,8 @@ template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3,
 template <> struct StaticShape<4> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 3; };
 template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
+template <> struct StaticShape<12> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 4; };
+template <> struct StaticShape<13> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 3, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 1, KW = 3, LW = 4, LH = 3, LD = 0; };
 
@@ -64,7 +67,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr int SLP = SL + 1;          // ... plus one pad slot (bank spreading; also fetched, from the zero page)
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
     // halo pieces per thread whose source offsets are kept in registers (the big halos of the mask conv / 4x4x16 tiles too)
-    constexpr int HI = ST == 4 ? 18 : (ST == 3 ? 13 : 8);
+    constexpr int HI = ST == 4 ? 18 : (ST == 3 ? 13 : (ST == 12 ? 9 : 8));
     constexpr int KH32 = CK / 32;        // 32-channel K-steps per tap and chunk
     constexpr int PFD = 4;               // weight prefetch depth in K-steps
     constexpr int SKS = SK ? 4 : 1;      // K-step stride of one wave
@@ -437,6 +440,10 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
     // candidate static shape for this launch
     if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
     const int stv = p.KD == 1 ? 1 : (p.KD == 7 ? (p.lgTW == 1 ? 6 : 4) : (p.lgTD == 4 ? 3 : (p.lgTD == 3 ? 5 : 2)));
+    if (p.KD == 3 && p.KH == 2 && p.KW == 2 && ck == 32 && mode == MODE_STD) {
+        if (cfg == CFG_H_256x32) return launch_halo_cfg<32, 4, 2, 4, 1, MODE_STD, false, 12>(p, st);
+        if (cfg == CFG_H_128x64) return launch_halo_cfg<32, 4, 2, 2, 2, MODE_STD, false, 13>(p, st);
+    }
     if (cfg == CFG_H_128x128 && mode == MODE_STD && ck == 64 && p.KD == 1 && p.KW == 3 && (p.KH == 2 || p.KH == 1)) {
         if (p.KH == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 10>(p, st);
         return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 11>(p, st);

@@ -61,6 +61,7 @@ struct cs_engine {
     struct RB3 { ConvL c1, c2; Affine post; } f_rb[6], t_rb[6];
     const float *cmp_w = nullptr, *cmp_b = nullptr;
     ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_occ, w_third, w_fourth;
+    ConvL w_dec_p[2][4];                   // up-blocks 3 and 4 per output phase (a, b) on the source grid
     float occ_b = 0.f;
     const float* mask_b = nullptr;
     TLayer t_l[14];
@@ -391,11 +392,23 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         ConvCall c = mk(e->w_dec[i], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, S, S, 1);
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_l[lv - 1], FD, S, S, lw[lv - 1]);
-        if (i == 4) {   // 128 -> 32 channels at full resolution: the 256-position x 32-channel tile (4x4x16 positions) issues twice the
-            c.hcfg = CFG_H_256x32;                       // MFMAs per weight fragment of the 128x32 one: 0.47 -> 0.27 ms at B = 16
-            TRY(go(e, c, st, 4, 4));
+        static const bool direct = getenv("CANONSWAP_DEC_DIRECT") != nullptr;     // A/B knob: 3x3x3 conv on the up-sampled grid
+        if (i >= 3 && !direct) {
+            // the nearest (1,2,2) up-sampling makes the three row / column taps read two source rows / columns: one 3x2x2 conv per
+            // output phase (y, x) = (2i + a, 2j + b) on the source grid, 12 of 27 taps (pack.upsampled_conv3d_phases)
+            const int lwo = lw[lv - 1];
+            for (int ab = 0; ab < 4; ++ab) {
+                const int a = ab >> 1, b = ab & 1;
+                ConvCall q = mk(e->w_dec_p[i - 3][ab], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
+                q.p.PH = a == 0; q.p.PW = b == 0;
+                q.p.act0 = ACT_RELU;
+                q.p.out0 = td(e->dm_l[lv - 1] + ((long)a * S + b) * lwo, (long)FD * S * S * lwo, (long)S * S * lwo, 2L * S * lwo, 2L * lwo);
+                if (i == 4) { q.hcfg = CFG_H_256x32; TRY(go(e, q, st, 4, 4)); }     // 32 output channels: 256-position tile
+                else TRY(go(e, q, st));
+            }
             continue;
         }
+        if (i == 4) { c.hcfg = CFG_H_256x32; TRY(go(e, c, st, 4, 4)); continue; }
         TRY(go(e, c, st));
     }
     ConvCall t = mk(e->w_tail, e->dm_l[0], dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // util.py:261-263
@@ -826,6 +839,11 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     for (int i = 0; i < 5; ++i) {
         snprintf(n, sizeof n, "W.enc%d", i); TRY(get_conv(e, n, eci[i], eco[i], eco[i], 3, 3, 3, eco[i], (double)ecr[i] * eco[i] * 27, &e->w_enc[i]));
         snprintf(n, sizeof n, "W.dec%d", i); TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 3, 3, dco[i], (double)dci[i] * dco[i] * 27, &e->w_dec[i]));
+        for (int ab = 0; i >= 3 && ab < 4; ++ab) {      // algorithmic MACs per (source) position stay those of the 3x3x3 conv
+            snprintf(n, sizeof n, "W.dec%d.p%d%d", i, ab >> 1, ab & 1);
+            TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 2, 2, 0, (double)dci[i] * dco[i] * 27, &e->w_dec_p[i - 3][ab]));
+            e->w_dec_p[i - 3][ab].b = e->w_dec[i].b;
+        }
     }
     TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));

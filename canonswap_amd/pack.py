@@ -128,6 +128,9 @@ def _pack_W(out, sd):
             w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
             out[f"W.{kind}{i}.w"] = pack_conv(w, w.shape[0])
             out[f"W.{kind}{i}.b"] = _f32(b)
+            if kind == "dec" and i >= 3:     # the two large up-blocks run per output phase on the source grid (engine.hip)
+                for (a, bb), (_, _, wab) in upsampled_conv3d_phases(w).items():
+                    out[f"W.dec{i}.p{a}{bb}.w"] = pack_conv(wab, wab.shape[0])
     q = p + ".hourglass.decoder"
     s, t = bn_affine(sd, q + ".norm")
     w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
@@ -219,6 +222,24 @@ def upsampled_conv_phases(w, s):
                 for dx in range(3):
                     wa[b * co:(b + 1) * co, :, rows.index(off(a, dy)), off(b, dx) + 1] += w[:, :, dy, dx]
         res.append((len(rows), -rows[0], wa))
+    return res
+
+
+def upsampled_conv3d_phases(w):
+    """3x3x3 'same' conv after a nearest (1,2,2) up-sampling (UpBlock3d, util.py:142-147) as four convs on the SOURCE grid, one
+    per output phase (a, b) of (y, x) = (2i + a, 2j + b): the three row / column taps collapse onto the two source rows /
+    columns they read (12 of 27 taps).  Returns {(a, b): (PH, PW, w_ab [Co][Ci][3][2][2])}; zero padding carries over."""
+    w = np.asarray(w, np.float64)
+    off = lambda ph, d: (ph + d - 1) // 2
+    res = {}
+    for a in range(2):
+        for b in range(2):
+            rows = sorted({off(a, d) for d in range(3)}); cols = sorted({off(b, d) for d in range(3)})
+            wab = np.zeros(w.shape[:3] + (2, 2), np.float64)
+            for dy in range(3):
+                for dx in range(3):
+                    wab[:, :, :, rows.index(off(a, dy)), cols.index(off(b, dx))] += w[:, :, :, dy, dx]
+            res[(a, b)] = (-rows[0], -cols[0], wab)
     return res
 
 

@@ -112,3 +112,16 @@ def test_upsampled_conv_phase_decomposition(s):
         for b in range(s):
             out[:, :, a::s, b::s] = y[:, b * 5:(b + 1) * 5]
     assert np.abs(out - ref).max() < 1e-12
+
+
+def test_upsampled_conv3d_phase_decomposition():
+    """pack.upsampled_conv3d_phases: 3x3x3 conv after a nearest (1,2,2) up-sampling == four 3x2x2 convs on the source grid."""
+    r = np.random.Generator(np.random.PCG64(9))
+    w, x = r.standard_normal((5, 3, 3, 3, 3)), r.standard_normal((1, 3, 4, 6, 6))
+    ref = F.conv3d(F.interpolate(torch.from_numpy(x), scale_factor=(1, 2, 2), mode="nearest"), torch.from_numpy(w), padding=1).numpy()
+    out = np.zeros_like(ref)
+    for (a, b), (ph, pw, wab) in pack.upsampled_conv3d_phases(w).items():
+        assert (ph, pw) == (int(a == 0), int(b == 0)) and wab.shape == (5, 3, 3, 2, 2)
+        xp = F.pad(torch.from_numpy(x), (pw, 1 - pw, ph, 1 - ph, 1, 1))
+        out[:, :, :, a::2, b::2] = F.conv3d(xp, torch.from_numpy(wab)).numpy()
+    assert np.abs(out - ref).max() < 1e-12
