@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "32")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: dry run of the multi-rank flow with all ranks sharing GPU 0 and host-side collectives (test only)")
     a = ap.parse_args()
 
     import torch
@@ -42,11 +44,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs a {a.gpus}-rank launch (WORLD_SIZE={world}); use torch.distributed.run")
+    share_gpu = a.backend == "gloo"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if share_gpu else dev        # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     B, K, Wm = a.batch, a.steps, a.warmup
     sds = synth.to_torch(synth.make_state_dicts(0))                     # random-init weights of the real architecture
@@ -54,8 +63,9 @@ def main():
     eng = sw.engine
 
     # one-time broadcast of the source identity (2 KB); every rank derives T's modulated weights locally
-    sid = torch.from_numpy(synth.make_identity(7)).to(dev) if rank == 0 else torch.zeros(1, 512, device=dev)
+    sid = torch.from_numpy(synth.make_identity(7)).to(cdev) if rank == 0 else torch.zeros(1, 512, device=cdev)
     parallel.broadcast_identity(sid, src=0)
+    sid = sid.to(dev)
     eng.set_identity(sid)
 
     # synthetic inputs resident in HBM: a pool of 4 distinct batches per rank, cycled over the steps
@@ -81,11 +91,11 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         step(i, i)
-    gathered = parallel.gather_frames(out_u8, K * B * world, dst=0) if world > 1 else out_u8   # final gather over xGMI
+    gathered = parallel.gather_frames(out_u8.to(cdev), K * B * world, dst=0) if world > 1 else out_u8   # final gather over xGMI
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
