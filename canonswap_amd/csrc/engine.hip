@@ -559,7 +559,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     fc.p.out0 = nhwc(e->g_x[0], 64, 64, 512);
     float* sx = nullptr;             // (mean, rstd) of the current x, produced by the epilogue of the conv that wrote it
     TRY(go_stats(e, fc, 512, 4096, &sx, st));
-    // all 18 mlp_shared convs depend only on seg (util.py:298): three fused launches
+    // all 18 mlp_shared convs depend only on seg (util.py:298): run up front, the twelve 64x64 ones as one launch
     ConvCall s64 = mk(e->g_sh64, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
     s64.p.act0 = ACT_RELU; s64.p.out0 = nhwc(e->g_a64, 64, 64, 1536);
     TRY(go(e, s64, st));
