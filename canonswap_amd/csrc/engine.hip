@@ -430,6 +430,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
     oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 16); oc.p.out0_f32 = 1;
     if (halo_enabled()) {
+        oc.hcfg = CFG_H_SK128x32;     // 7 real output channels, 560 K-steps: the four waves split the K-steps (0.27 -> 0.20 ms at B = 16)
         TRY(go(e, oc, st));
     } else {
         cs_set_error("the occlusion conv needs conv_halo (grouped input channels)");
@@ -848,7 +849,7 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));
     TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
-    TRY(get_conv(e, "W.occp", 16 * 160, 16, 16, 1, 7, 1, 0, 2272.0 * 49, &e->w_occ));
+    TRY(get_conv(e, "W.occp", 16 * 160, 32, 16, 1, 7, 1, 0, 2272.0 * 49, &e->w_occ));
     { const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
       CS_CHECK_HIP(hipMemcpy(&e->occ_b, b->p, 4, hipMemcpyDeviceToHost)); }
     TRY(get_conv(e, "W.third", 512, 256, 256, 1, 3, 3, 256, 512.0 * 256 * 9, &e->w_third));

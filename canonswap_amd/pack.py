@@ -147,7 +147,7 @@ def _pack_W(out, sd):
     #   w'[kx][d*160 + c][ky][0] = W_occ[0][c*16 + d][ky][kx]
     wg = np.zeros((7, 16, 160, 7, 1), np.float32)
     wg[:, :, :142, :, 0] = wo.transpose(3, 1, 0, 2)                  # [kx][d][c][ky]
-    out["W.occp.w"] = pack_conv(wg.reshape(7, 16 * 160, 7, 1), 16)
+    out["W.occp.w"] = pack_conv(wg.reshape(7, 16 * 160, 7, 1), 32)
     out["W.occ.b"] = _f32(sd[p + ".occlusion.bias"].reshape(1))
     s, t = bn_affine(sd, "third.norm")
     w, b = fold_conv_bn(sd["third.conv.weight"][:, MEM2REF], sd["third.conv.bias"], s, t)
