@@ -39,7 +39,7 @@ __device__ __forceinline__ void wait_vmcnt_le()
 //   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
 //   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
 //   ST 12 / 13: 3x2x2, tiles 4x4x16 and 8x8x2 (the hourglass up-blocks per output phase on the source grid)
-//   ST 10 / 11: 1x2x3 and 1x1x3, tile 16x8 (the row-phase convs of mlp_shared on the up-sampled seg, engine.hip run_G)
+//   ST 10 / 11 / 14 / 15: 1x2x2, 1x2x1, 1x1x2, 1x1x1, tile 16x8 (the per-phase convs of mlp_shared on the up-sampled seg, run_G)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
@@ -49,8 +49,10 @@ template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3,
 template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
 template <> struct StaticShape<12> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 4; };
 template <> struct StaticShape<13> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 3, LH = 3, LD = 1; };
-template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 3, LW = 4, LH = 3, LD = 0; };
-template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 1, KW = 3, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 2, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 2, KW = 1, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<14> { static constexpr int KD = 1, KH = 1, KW = 2, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<15> { static constexpr int KD = 1, KH = 1, KW = 1, LW = 4, LH = 3, LD = 0; };
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 // Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
@@ -444,9 +446,11 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
         if (cfg == CFG_H_256x32) return launch_halo_cfg<32, 4, 2, 4, 1, MODE_STD, false, 12>(p, st);
         if (cfg == CFG_H_128x64) return launch_halo_cfg<32, 4, 2, 2, 2, MODE_STD, false, 13>(p, st);
     }
-    if (cfg == CFG_H_128x128 && mode == MODE_STD && ck == 64 && p.KD == 1 && p.KW == 3 && (p.KH == 2 || p.KH == 1)) {
-        if (p.KH == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 10>(p, st);
-        return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 11>(p, st);
+    if (cfg == CFG_H_128x128 && mode == MODE_STD && ck == 64 && p.KD == 1 && p.KH <= 2 && p.KW <= 2) {
+        if (p.KH == 2 && p.KW == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 10>(p, st);
+        if (p.KH == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 11>(p, st);
+        if (p.KW == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 14>(p, st);
+        return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 15>(p, st);
     }
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \
     if (cfg == CFG && mode == MODE) {                                                                    \

@@ -69,8 +69,8 @@ struct cs_engine {
     struct S3 { ConvL c1, c2; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];
     struct RB2 { ConvL c1, c2; Affine pre; } r_rb2[3];
     ConvL g_fc, g_sh64, g_sh128, g_sh256, g_img;
-    ConvL g_sh128p[2], g_sh256p[4];        // mlp_shared convs of the up blocks per output row phase on the source grid
-    int g_shp_ph[2][4] = {};               // their top padding
+    struct ShPhase { ConvL conv; int a, b0, ph, pw; };     // mlp_shared convs of the up blocks per output phase group on the source grid
+    ShPhase g_shp[2][12]; int g_nshp[2] = {0, 0};
     struct GB { ConvL conv; const float *bg, *bb; };
     struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs; bool learned; int fin, fmid, fout; } g_blk[8];
 
@@ -565,7 +565,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     s64.p.act0 = ACT_RELU; s64.p.out0 = nhwc(e->g_a64, 64, 64, 1536);
     TRY(go(e, s64, st));
     // mlp_shared of the up blocks reads seg nearest-resized to 128 / 256 (util.py:297-298): run per output row phase on the 64x64
-    // source grid, column phases as output-channel blocks (pack.upsampled_conv_phases): 6/9 and 18/36 of the taps, same result
+    // source grid and per group of column phases (pack.upsampled_conv_phases): 16/36 and 36/144 of the taps, same result
     static const bool direct = getenv("CANONSWAP_SHARED_DIRECT") != nullptr;     // A/B knob: 3x3 convs on the up-sampled grid
     for (int lv = 0; lv < 2; ++lv) {
         const int sc = lv ? 4 : 2, S = 64 * sc;
@@ -576,12 +576,13 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
             TRY(go(e, c, st));
             continue;
         }
-        for (int a = 0; a < sc; ++a) {
-            ConvCall c = mk(lv ? e->g_sh256p[a] : e->g_sh128p[a], seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
-            c.p.PH = e->g_shp_ph[lv][a];
+        for (int k = 0; k < e->g_nshp[lv]; ++k) {
+            const cs_engine::ShPhase& P = e->g_shp[lv][k];
+            ConvCall c = mk(P.conv, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
+            c.p.PH = P.ph; c.p.PW = P.pw;
             c.p.act0 = ACT_RELU;
-            // output pixel (sc*i + a, sc*j + b), channel c  <-  source position (i, j), channel b*384 + c
-            c.p.out0 = td(dst + (long)a * S * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+            // output pixel (sc*i + a, sc*j + b0 + k), channel c  <-  source position (i, j), channel k*384 + c
+            c.p.out0 = td(dst + ((long)P.a * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
             TRY(go(e, c, st));
         }
     }
@@ -891,14 +892,21 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     TRY(get_conv(e, "G.shared64", 256, 1536, 1536, 1, 3, 3, 1536, 256.0 * 1536 * 9, &e->g_sh64));
     TRY(get_conv(e, "G.shared128", 256, 384, 384, 1, 3, 3, 384, 256.0 * 384 * 9, &e->g_sh128));
     TRY(get_conv(e, "G.shared256", 256, 384, 384, 1, 3, 3, 384, 256.0 * 384 * 9, &e->g_sh256));
-    for (int lv = 0; lv < 2; ++lv) {
+    for (int lv = 0; lv < 2; ++lv) {      // pack.upsampled_conv_phases: row phase a x groups of column phases with equal source columns
         const int sc = lv ? 4 : 2;
+        e->g_nshp[lv] = 0;
         for (int a = 0; a < sc; ++a) {
-            const int kh = (a == 0 || a == sc - 1) ? 2 : 1;           // rows {-1,0}, {0}, ..., {0,+1}
-            e->g_shp_ph[lv][a] = a == 0 ? 1 : 0;
-            snprintf(n, sizeof n, "G.shared%d.p%d", lv ? 256 : 128, a);
-            // algorithmic MACs stay those of the 3x3 conv on the up-sampled grid: sc*sc output pixels per source position, split over sc launches
-            TRY(get_conv(e, n, 256, sc * 384, sc * 384, 1, kh, 3, sc * 384, 256.0 * 384 * 9 * sc, lv ? &e->g_sh256p[a] : &e->g_sh128p[a]));
+            const int kh = (a == 0 || a == sc - 1) ? 2 : 1, ph = a == 0 ? 1 : 0;
+            for (int b0 = 0; b0 < sc; ) {
+                const bool edge = b0 == 0 || b0 == sc - 1;
+                const int nb = edge ? 1 : sc - 2, kw = edge ? 2 : 1, pw = b0 == 0 ? 1 : 0;
+                cs_engine::ShPhase& P = e->g_shp[lv][e->g_nshp[lv]++];
+                P.a = a; P.b0 = b0; P.ph = ph; P.pw = pw;
+                snprintf(n, sizeof n, "G.shared%d.p%d%d", lv ? 256 : 128, a, b0);
+                // algorithmic MACs stay those of the 3x3 conv on the up-sampled grid: nb*sc... output pixels per source position
+                TRY(get_conv(e, n, 256, nb * 384, nb * 384, 1, kh, kw, nb * 384, 256.0 * 384 * 9 * nb, &P.conv));
+                b0 += nb;
+            }
         }
     }
     auto get_gb = [&](const std::string& b, int C, cs_engine::GB* gb) -> int {

@@ -205,23 +205,33 @@ def _pack_gb(out, n, sd, p):
 
 
 def upsampled_conv_phases(w, s):
-    """3x3 'same' conv applied to a nearest-x`s` up-sampled map (SPADE resizes seg to x's size, util.py:297-298) as `s` convs on
-    the SOURCE grid, one per output row phase a (y = s*i + a): row taps collapse to the 1-2 source rows they read, the column
-    phases b become output-channel blocks with a 3-wide column kernel (zero where a phase does not use a source column).
-    Exact: taps that land on the same source pixel add their weights; zero padding of the up-sampled map is zero padding of
-    the source grid.  Returns [(KH, PH, w_a [s*Co][Ci][KH][3])] for a = 0..s-1; output channel = b*Co + co."""
+    """3x3 'same' conv applied to a nearest-x`s` up-sampled map (SPADE resizes seg to x's size, util.py:297-298) as convs on the
+    SOURCE grid, one per output row phase a (y = s*i + a) and group of column phases that read the same source columns
+    (s = 2: b = 0 | 1;  s = 4: b = 0 | 1,2 | 3): taps that land on the same source pixel add their weights, so a phase keeps
+    only the 1-2 source rows / columns it reads (16 of 36 taps for s = 2, 36 of 144 for s = 4).  The column phases of a group
+    are adjacent output pixels and become output-channel blocks.  Exact; zero padding of the up-sampled map is zero padding
+    of the source grid.  Returns [(a, b0, nb, KH, PH, KW, PW, w [nb*Co][Ci][KH][KW])]; output channel = (b - b0)*Co + co."""
     w = np.asarray(w, np.float64)
     co, ci = w.shape[:2]
     off = lambda ph, d: (ph + d - 1) // s            # source offset (-1, 0, +1) read by tap d of output phase ph
+    taps = lambda ph: tuple(sorted({off(ph, d) for d in range(3)}))
+    groups = []                                      # runs of column phases with identical source-column sets
+    for b in range(s):
+        if groups and taps(groups[-1][0]) == taps(b):
+            groups[-1].append(b)
+        else:
+            groups.append([b])
     res = []
     for a in range(s):
-        rows = sorted({off(a, dy) for dy in range(3)})
-        wa = np.zeros((s * co, ci, len(rows), 3), np.float64)
-        for b in range(s):
-            for dy in range(3):
-                for dx in range(3):
-                    wa[b * co:(b + 1) * co, :, rows.index(off(a, dy)), off(b, dx) + 1] += w[:, :, dy, dx]
-        res.append((len(rows), -rows[0], wa))
+        rows = taps(a)
+        for g in groups:
+            cols = taps(g[0])
+            wg = np.zeros((len(g) * co, ci, len(rows), len(cols)), np.float64)
+            for k, b in enumerate(g):
+                for dy in range(3):
+                    for dx in range(3):
+                        wg[k * co:(k + 1) * co, :, rows.index(off(a, dy)), cols.index(off(b, dx))] += w[:, :, dy, dx]
+            res.append((a, g[0], len(g), len(rows), -rows[0], len(cols), -cols[0], wg))
     return res
 
 
@@ -257,9 +267,9 @@ def _pack_G(out, sd):
         out[n + ".b"] = _f32(np.concatenate([sd[q + ".mlp_shared.0.bias"] for q in lst]))
         s_up = {"G.shared128": 2, "G.shared256": 4}.get(n)
         if s_up:      # the same convs per output row phase on the 64x64 source grid (2.25x / 4x fewer taps, engine.hip run_G)
-            for a, (kh, ph, wa) in enumerate(upsampled_conv_phases(w, s_up)):
-                out[f"{n}.p{a}.w"] = pack_conv(wa, wa.shape[0])
-                out[f"{n}.p{a}.b"] = _f32(np.tile(out[n + ".b"], s_up))
+            for a, b0, nb, kh, ph, kw, pw, wg in upsampled_conv_phases(w, s_up):
+                out[f"{n}.p{a}{b0}.w"] = pack_conv(wg, wg.shape[0])
+                out[f"{n}.p{a}{b0}.b"] = _f32(np.tile(out[n + ".b"], nb))
     blocks = [(f"G.m{b}", f"G_middle_{b}") for b in range(6)] + [("G.up0", "up_0"), ("G.up1", "up_1")]
     for n, p in blocks:
         for k in ("0", "1"):

@@ -106,11 +106,12 @@ def test_upsampled_conv_phase_decomposition(s):
     ref = F.conv2d(F.interpolate(torch.from_numpy(x), scale_factor=s, mode="nearest"), torch.from_numpy(w), padding=1).numpy()
     out = np.zeros_like(ref)
     phases = pack.upsampled_conv_phases(w, s)
-    assert [kh for kh, _, _ in phases] == ([2, 2] if s == 2 else [2, 1, 1, 2])
-    for a, (kh, ph, wa) in enumerate(phases):
-        y = F.conv2d(F.pad(torch.from_numpy(x), (1, 1, ph, kh - 1 - ph)), torch.from_numpy(wa)).numpy()
-        for b in range(s):
-            out[:, :, a::s, b::s] = y[:, b * 5:(b + 1) * 5]
+    assert len(phases) == (4 if s == 2 else 12)
+    for a, b0, nb, kh, ph, kw, pw, wg in phases:
+        assert wg.shape == (nb * 5, 3, kh, kw)
+        y = F.conv2d(F.pad(torch.from_numpy(x), (pw, kw - 1 - pw, ph, kh - 1 - ph)), torch.from_numpy(wg)).numpy()
+        for k in range(nb):
+            out[:, :, a::s, b0 + k::s] = y[:, k * 5:(k + 1) * 5]
     assert np.abs(out - ref).max() < 1e-12
 
 
