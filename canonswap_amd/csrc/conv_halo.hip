@@ -446,6 +446,13 @@ int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t
         if (cfg == CFG_H_256x32) return launch_halo_cfg<32, 4, 2, 4, 1, MODE_STD, false, 12>(p, st);
         if (cfg == CFG_H_128x64) return launch_halo_cfg<32, 4, 2, 2, 2, MODE_STD, false, 13>(p, st);
     }
+    if (mode == MODE_STD && p.KD == 1 && p.KH == 1 && p.KW == 1) {      // 1x1 convs (shortcuts, the motion extractor's linear layers)
+        if (cfg == CFG_H_128x128 && ck == 32) return launch_halo_cfg<32, 8, 2, 1, 4, MODE_STD, false, 15>(p, st);
+        if (cfg == CFG_H_128x64 && ck == 64) return launch_halo_cfg<64, 4, 2, 2, 2, MODE_STD, false, 15>(p, st);
+        if (cfg == CFG_H_128x64 && ck == 32) return launch_halo_cfg<32, 4, 2, 2, 2, MODE_STD, false, 15>(p, st);
+        if (cfg == CFG_H_128x32 && ck == 64) return launch_halo_cfg<64, 2, 2, 4, 1, MODE_STD, false, 15>(p, st);
+        if (cfg == CFG_H_128x32 && ck == 32) return launch_halo_cfg<32, 2, 2, 4, 1, MODE_STD, false, 15>(p, st);
+    }
     if (cfg == CFG_H_128x128 && mode == MODE_STD && ck == 64 && p.KD == 1 && p.KH <= 2 && p.KW <= 2) {
         if (p.KH == 2 && p.KW == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 10>(p, st);
         if (p.KH == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 11>(p, st);
