@@ -64,8 +64,47 @@ _Pragma("unroll") \
     for (int ci = 0; ci < EP_SC; ++ci) \
 _Pragma("unroll") \
         for (int r = 0; r < 4; ++r) { ep_sum[ci][r] = 0.f; ep_sq[ci][r] = 0.f; } \
+    /* The residual / modulated tensor is fetched for EP_G position blocks at a time BEFORE any of their stores: inside the \
+       per-block loop every load would wait for its own round trip (hipcc may not hoist a load above the previous block's \
+       stores, res and out0 may alias) - 8 to 16 serialised memory latencies per wave.  In-place use (res == out0) stays \
+       correct: a lane reads exactly the elements it later writes. */ \
+    /* Compiled in only for the 256x32 STD kernel (the residual convs of the ResBlock3d chains, -9 % there): elsewhere the extra \
+       live registers cost an occupancy step (mask / tail convs +30..40 %, SPADE +5 %), measured per layer. */ \
+    constexpr bool EP_PF = (MODE == MODE_STD) && (WCH == 2) && (EP_WPX == 4); \
+    constexpr int EP_G = EP_PF ? 4 : 1; \
+    constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
+    const bool ep_fetch = EP_PF && p.res.p != nullptr; \
+    const int ep_rshift = 0; \
 _Pragma("unroll") \
-    for (int pi = 0; pi < EP_WPX; ++pi) { \
+    for (int pg = 0; pg < EP_WPX; pg += EP_G) { \
+    f4_t ep_raw32[EP_G][EP_NCI]; h4_t ep_raw16[EP_G][EP_NCI]; float ep_ps[EP_G]; \
+    if (EP_PF && (ep_fetch || p.pixscale)) { \
+_Pragma("unroll") \
+        for (int g = 0; g < EP_G; ++g) { \
+            int m = ep_wpx * EP_WPX * 16 + (pg + g) * 16 + l15; \
+            const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
+            const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
+            const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD; \
+            const int n = tn * (BM >> lgS) + m; \
+            if (n >= p.N) continue; \
+            if (p.pixscale) ep_ps[g] = p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
+            if (ep_fetch) { \
+_Pragma("unroll") \
+                for (int ci = 0; ci < WCH; ci += CSTEP) { \
+                    const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
+                    const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+                    if (cb >= p.Cout) continue; \
+                    const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> ep_rshift) * p.res.sH + \
+                                    (long)(w >> ep_rshift) * p.res.sW + cb; \
+                    if (p.res_f32) ep_raw32[g][(EP_PF ? ci / CSTEP : 0)] = *(const f4_t*)((const float*)p.res.p + xo); \
+                    else ep_raw16[g][(EP_PF ? ci / CSTEP : 0)] = *(const h4_t*)((const half_t*)p.res.p + xo); \
+                } \
+            } \
+        } \
+    } \
+_Pragma("unroll") \
+    for (int g = 0; g < EP_G; ++g) { \
+        const int pi = pg + g; \
         int m = ep_wpx * EP_WPX * 16 + pi * 16 + l15; \
         const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
         const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
@@ -73,7 +112,7 @@ _Pragma("unroll") \
         const int n = tn * (BM >> lgS) + m; \
         if (n >= p.N) continue; \
         float ps = 1.f; \
-        if (p.pixscale) ps = p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
+        if (p.pixscale) ps = EP_PF ? ep_ps[g] : p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
             const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
@@ -113,10 +152,15 @@ _Pragma("unroll") \
                 continue; \
             } \
             if (MODE != MODE_SPADE && p.res.p) { \
-                float rr[4]; \
-                load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)h * p.res.sH + (long)w * p.res.sW + cb, rr); \
+                if (EP_PF) { \
 _Pragma("unroll") \
-                for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
+                    for (int r = 0; r < 4; ++r) v[r] += p.res_f32 ? ep_raw32[g][(EP_PF ? ci / CSTEP : 0)][r] : (float)ep_raw16[g][(EP_PF ? ci / CSTEP : 0)][r]; \
+                } else { \
+                    float rr[4]; \
+                    load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)h * p.res.sH + (long)w * p.res.sW + cb, rr); \
+_Pragma("unroll") \
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
+                } \
             } \
             if ((MODE == MODE_STD || MODE == MODE_STDSTAT) && p.pixscale) { \
 _Pragma("unroll") \
@@ -141,6 +185,7 @@ _Pragma("unroll") \
                 store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u); \
             } \
         } \
+    } \
     } \
     if (EP_STAT) { /* fixed-order butterfly over the 16 position lanes, then one partial per (tile, wave, channel) */ \
         const int ep_tiles = p.nTW * p.nTH * p.nTD; \
