@@ -10,27 +10,76 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(HERE, "csrc", f) for f in ("conv_igemm.hip", "conv_halo.hip", "kernels.hip", "motion.hip", "engine.hip")]
-HEADERS = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "conv_epilogue.h"), os.path.join(os.path.dirname(HERE), "include", "canonswap_hip.h")]
-LIB_PATH = os.path.join(HERE, "libcanonswap_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_halo.hip", "kernels.hip", "motion.hip", "engine.hip")]
+HEADERS = [os.path.join(CSRC, f) for f in ("common.h", "conv_epilogue.h", "conv_halo_kernel.h")] + \
+          [os.path.join(os.path.dirname(HERE), "include", "canonswap_hip.h")]
+HALO_NGROUPS = 8          # conv_halo.hip is compiled once per -DHALO_GROUP=k (slices of its instantiation table)
+OBJ_DIR = os.path.join(HERE, "build")
+LIB_PATH = os.environ.get("CANONSWAP_LIB") or os.path.join(HERE, "libcanonswap_hip.so")      # CANONSWAP_LIB: A/B builds (tools/)
 ABI_SYMBOLS = [
     "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity",
-    "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_refine", "cs_warp_forward", "cs_spade_decode",
+    "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_unpack_u8", "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_op_conv", "cs_op_grid_sample3d",
     "cs_op_chan_stats", "cs_op_chan_stats_partial_floats",
 ]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
-def build(force: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into canonswap_amd/libcanonswap_hip.so (hipcc cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+def _units():
+    """(source, object name, extra flags) of every translation unit."""
+    units = []
+    for src in SOURCES:
+        base = os.path.splitext(os.path.basename(src))[0]
+        if base == "conv_halo":
+            units += [(src, f"conv_halo_g{g}.o", [f"-DHALO_GROUP={g}"]) for g in range(HALO_NGROUPS)]
+        else:
+            units.append((src, base + ".o", []))
+    return units
+
+
+def build(force: bool = False, lib_path: str | None = None, extra_flags=(), obj_dir: str | None = None, jobs: int | None = None) -> str:
+    """Compile the HIP sources for gfx950 into canonswap_amd/libcanonswap_hip.so (hipcc cross-compiles without a GPU).
+
+    Objects are cached under canonswap_amd/build/ and rebuilt when their source, any header or the flags changed; the
+    translation units compile in parallel."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib_path = lib_path or LIB_PATH
+    obj_dir = obj_dir or OBJ_DIR
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *SOURCES, "-o", LIB_PATH]
-    subprocess.run(cmd, check=True)
-    return LIB_PATH
+    flags = HIPCC_FLAGS + list(extra_flags)
+    stamp = " ".join([hipcc] + flags)
+    hdr_time = max(os.path.getmtime(p) for p in HEADERS)
+    todo, objs = [], []
+    for src, oname, extra in _units():
+        obj = os.path.join(obj_dir, oname)
+        objs.append(obj)
+        tag = obj + ".flags"
+        fresh = (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_time, os.path.getmtime(src))
+                 and os.path.exists(tag) and open(tag).read() == stamp + " " + " ".join(extra))
+        if not fresh:
+            todo.append((src, obj, extra, tag))
+
+    def compile_one(job):
+        src, obj, extra, tag = job
+        subprocess.run([hipcc, *flags, *extra, "-c", src, "-o", obj], check=True)
+        with open(tag, "w") as f:
+            f.write(stamp + " " + " ".join(extra))
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(compile_one, todo))
+    if todo or not os.path.exists(lib_path) or os.path.getmtime(lib_path) < max(os.path.getmtime(o) for o in objs):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path], check=True)
+    return lib_path
+
+
+def toolchain() -> str:
+    """hipcc version string (recorded by build(): the dynamic-shape conv kernels rely on hand-counted waits, see conv_halo_kernel.h)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    return " | ".join(l.strip() for l in out.splitlines() if "version" in l.lower())[:200]
 
 
 class ConvDesc(C.Structure):
@@ -50,10 +99,11 @@ class ConvDesc(C.Structure):
         ("s2", C.c_void_p), ("t2", C.c_void_p), ("act1", C.c_int), ("slope1", C.c_float),
         ("out1", C.c_void_p), ("out1_sN", C.c_long), ("out1_sD", C.c_long), ("out1_sH", C.c_long), ("out1_sW", C.c_long),
         ("stats", C.c_void_p),
-        ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int),
+        ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int), ("xcd_map", C.c_int),
     ]
 
 
+MAX_IDENTITY_SLOTS = 8      # CS_MAX_IDENTITY_SLOTS (include/canonswap_hip.h)
 _lib = None
 
 
@@ -79,6 +129,8 @@ def load():
     lib.cs_warp.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.cs_warp_out.argtypes = [vp, ci, vp, vp, vp, vp]
     lib.cs_swap.argtypes = [vp, ci, ci, vp, vp, vp]
+    lib.cs_swap_ids.argtypes = [vp, C.POINTER(ci), ci, vp, vp, vp]
+    lib.cs_swap_frames_ids.argtypes = [vp, C.POINTER(ci), ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cs_refine.argtypes = [vp, ci, vp, vp, vp]
     lib.cs_warp_forward.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.cs_spade_decode.argtypes = [vp, ci, vp, vp, vp]

@@ -5,8 +5,10 @@ Same constructor argument, attribute names, method names and tensor signatures a
 operation is executed by the gfx950 HIP engine (libcanonswap_hip.so) -- there is no PyTorch or CPU fallback.
 Stage attributes (``warping_module``, ``swap_module`` ...) are small callables bound to the C ABI.
 
-Outside the generator hot path ("next" rows): the motion extractor M (``get_kp_info``) and
-the ArcFace identity network (``getid``) are not part of this engine and raise NotImplementedError.
+The motion extractor M runs on the engine too (``get_kp_info``).  The ArcFace identity network
+behind ``getid`` (can_swap_e2e.py:80-84,102-107: a pickled third-party module, ``pretrained_weights/arcface_checkpoint.tar``) is
+outside the generator path: ``getid`` keeps the reference's arithmetic (nearest resize to 112x112, network, L2 normalisation)
+around a network the caller injects (``id_net=`` or ``can_swapper.netArc = ...``) and raises if there is none.
 """
 from __future__ import annotations
 
@@ -50,7 +52,7 @@ class _Callable:
 class can_swapper(object):
     """MI355X engine behind the reference's ``can_swapper`` interface."""
 
-    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8):
+    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8, id_net=None):
         self.inference_cfg = inference_cfg
         self.device_id = getattr(inference_cfg, "device_id", 0)
         self.compile = False                      # torch.compile switch of the reference (:47,:74-77) has no meaning here
@@ -64,6 +66,12 @@ class can_swapper(object):
         self.swap_module = _Callable(lambda f, source_id: self.engine.swap(f, source_id))
         self.refine_module = _Callable(self.engine.refine)
         self.motion_extractor = None
+        # identity extractor (:80-84): the reference unpickles an ArcFace module; here it is injected, or loaded from the same
+        # path when that file exists (torch.load of a pickled nn.Module needs the defining package importable, as in the reference)
+        self.netArc = id_net
+        arc = "pretrained_weights/arcface_checkpoint.tar"
+        if self.netArc is None and os.path.exists(arc):
+            self.netArc = torch.load(arc, map_location=torch.device("cpu"), weights_only=False).to(self.device).eval()
         if state_dicts is not None:
             self.load_state_dicts(state_dicts)
         else:
@@ -92,7 +100,15 @@ class can_swapper(object):
                 setattr(self.inference_cfg, k, v)
 
     def getid(self, img):
-        raise NotImplementedError("ArcFace identity extraction is outside the generator hot path; pass source_id (1x512)")
+        """can_swap_e2e.py:102-107: F.interpolate(img, (112, 112)) [nearest] -> netArc -> L2-normalised (B, 512) identity."""
+        if self.netArc is None:
+            raise RuntimeError("getid: no identity network (pass id_net= to can_swapper or set .netArc; the reference loads "
+                               "pretrained_weights/arcface_checkpoint.tar, which is outside the generator path)")
+        with torch.no_grad():
+            x = torch.nn.functional.interpolate(img, size=(112, 112))
+            out = self.netArc(x)
+            idv = out[0] if isinstance(out, (tuple, list)) else out
+            return torch.nn.functional.normalize(idv, p=2, dim=1)
 
     def get_kp_info(self, x, **kwargs):
         """can_swap_e2e.py:174-199: implicit key-point information of Bx3x256x256 images in [0,1]."""

@@ -16,7 +16,8 @@ enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
 // tile configurations of conv_halo
 enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 13, CFG_H_128x16 = 14, CFG_H_256x16 = 15,
        CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */, CFG_H_128x256 = 17,
-       CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */ };
+       CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */,
+       CFG_H_256x160 = 19 /* 2x2 waves of 128 positions x 80 channels, one workgroup per CU: half the weight bytes per MFMA of 128x160 */ };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {
@@ -43,6 +44,12 @@ struct ConvParams {
     int KD, KH, KW, PD, PH, PW;
     // packed weights [kstep][Cout_pad][32] fp16, kstep = ((chunk*KD+kd)*KH+kh)*KW+kw
     const half_t* wgt;
+    // per-sample weight sets (T's identity-modulated convs with several identities in one batch, adaptive_modulate.py:157-167
+    // groups=N): sample n uses the set at wgt + wofs[wslot[n]] (element offsets relative to wgt: plain pointer arithmetic on the
+    // kernel argument keeps the weight stream global_load; a pointer fetched from a table would make it flat_load, whose completion
+    // needs vmcnt(0) + lgkmcnt(0) and drains the prefetch ring at every K-step).  Tiles must lie within one sample.  nullptr: off.
+    const long* wofs;
+    const int* wslot;
     int Cout_pad;       // packed rows (multiple of the channel tile)
     int Cout;           // logical channels stored (multiple of 4)
     // M-tile decomposition: tile = TN x TD x TH x TW positions (all powers of two)
@@ -70,6 +77,16 @@ struct ConvParams {
     // Instance/GroupNorm: stat_out[((n*nblk + blk)*Cout + c)*2 + {0,1}], nblk = tiles per sample * waves along positions.
     // Finished by launch_chan_stats_finish (fixed order: deterministic). Requires tiles that lie within one sample.
     float* stat_out;
+    // workgroup -> (position tile, channel block) mapping (conv_halo): hardware places workgroup b on XCD b % 8 (each XCD has its
+    // own L2).  0: blockIdx.x = tile, blockIdx.y = channel block.  1: the same grid, but every XCD walks a contiguous range of
+    // tiles (halo overlaps of neighbouring tiles hit in that XCD's L2).  2: flat grid, contiguous range per XCD with the channel
+    // blocks of one tile adjacent (the input tile is fetched into the L2 once for all of them).
+    int xcd_map;
+#ifdef CS_TIMELINE
+    // instrumented builds only (tools/timeline.py): per-wave s_memtime stamps of the kernel's phases, 12 x u64 per wave
+    unsigned long long* tl;
+    long tl_cap;            // capacity in waves
+#endif
 };
 
 #define CS_CHECK_HIP(expr)                                                                  \

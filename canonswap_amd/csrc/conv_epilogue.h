@@ -4,6 +4,12 @@
 #pragma once
 #include "common.h"
 
+#ifndef EP_TL
+#define EP_TL(i) do { } while (0)      /* phase stamps of instrumented builds (conv_halo_kernel.h, -DCS_TIMELINE) */
+#endif
+typedef unsigned int ep_u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int ep_u2_t __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -12,6 +18,12 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     return v;
 }
+
+// ReLU / LeakyReLU / identity as ONE branch-free formula: slope 0 / s / 1 (bit-identical to the switch above for those three).
+// The epilogue is fully unrolled; a runtime switch per element (with the erf polynomial of GELU inlined each time) made it 18 000
+// instructions and ~1 800 branches long, fetch-bound at 13-38 % of a wave's lifetime (profiles/r02_timeline_*.txt).
+__device__ __forceinline__ float lin_act(float v, float slope) { return fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)); }
+__device__ __forceinline__ float lin_slope(int act, float slope) { return act == ACT_NONE ? 1.f : (act == ACT_LRELU ? slope : 0.f); }
 
 __device__ __forceinline__ void load4(const TDesc& t, int is_f32, long off, float v[4])
 {
@@ -36,8 +48,10 @@ __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, con
 }
 
 
+// EP_HEAVY (constexpr bool, in scope): this instantiation also carries sigmoid / GELU for act0 (launchers refuse those activations
+// on the others); act1 is always one of none / ReLU / LeakyReLU.
 // Expects in scope: p, ep_acc[WCH][EP_WPX] (f4_t), ep_wpx (position-block index of this wave), EP_WPX, n0, tw, th, td, tn,
-// lgS, mW, mH, mD, wch, l15, l4 and the template constants WCH, BM, MODE.
+// lgS, mW, mH, mD, wch, l15, l4, tile_lin (linear index of the position tile) and the template constants WCH, BM, MODE.
 #define CONV_EPILOGUE() \
     constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
     /* per-channel constants of this lane's 4 channels, loaded once (16-byte loads), not once per position block */ \
@@ -57,6 +71,7 @@ _Pragma("unroll") \
             ep_mean[ci] = make_float4(q0.x, q0.z, q1.x, q1.z); ep_rstd[ci] = make_float4(q0.y, q0.w, q1.y, q1.w); \
         } else { ep_mean[ci] = make_float4(0.f, 0.f, 0.f, 0.f); ep_rstd[ci] = make_float4(1.f, 1.f, 1.f, 1.f); } \
     } \
+    const float ep_sl0 = lin_slope(p.act0, p.slope0), ep_sl1 = lin_slope(p.act1, p.slope1); \
     constexpr bool EP_STAT = (MODE == MODE_STDSTAT); /* compile-time: the accumulators cost occupancy otherwise */ \
     constexpr int EP_SC = EP_STAT ? WCH : 1; \
     float ep_sum[EP_SC][4], ep_sq[EP_SC][4]; \
@@ -64,20 +79,23 @@ _Pragma("unroll") \
     for (int ci = 0; ci < EP_SC; ++ci) \
 _Pragma("unroll") \
         for (int r = 0; r < 4; ++r) { ep_sum[ci][r] = 0.f; ep_sq[ci][r] = 0.f; } \
-    /* The residual / modulated tensor is fetched for EP_G position blocks at a time BEFORE any of their stores: inside the \
-       per-block loop every load would wait for its own round trip (hipcc may not hoist a load above the previous block's \
-       stores, res and out0 may alias) - 8 to 16 serialised memory latencies per wave.  In-place use (res == out0) stays \
-       correct: a lane reads exactly the elements it later writes. */ \
-    /* Compiled in only for the 256x32 STD kernel (the residual convs of the ResBlock3d chains, -9 % there): elsewhere the extra \
-       live registers cost an occupancy step (mask / tail convs +30..40 %, SPADE +5 %), measured per layer. */ \
-    constexpr bool EP_PF = (MODE == MODE_STD) && (WCH == 2) && (EP_WPX == 4); \
-    constexpr int EP_G = EP_PF ? 4 : 1; \
+    /* Every fetch of the epilogue (residual / the tensor being modulated / per-position scale) for the WHOLE tile of the wave is \
+       issued before its first store.  vmcnt counts loads and stores alike and hipcc may not hoist a load above a store that might \
+       alias, so a load inside the per-block loop waits for its own round trip AND for the acknowledgement of every store issued \
+       before it: 8-16 serialised memory latencies per wave, 13-38 % of a wave's lifetime (profiles/r02_timeline_before.txt). \
+       The main loop's operand registers are dead here, so the staging registers are free.  In-place use (res == out0) stays \
+       correct: a lane reads exactly the elements it later writes.  Not compiled into the 160-wide tiles (WCH == 5: they never \
+       carry a residual and 80 more live registers would cost them an occupancy step). */ \
+    constexpr bool EP_PF = (WCH != 5); \
+    /* position blocks fetched per round: the whole tile where the register budget allows (no scratch, same occupancy step - \
+       checked with tools/kernel_resources.py), else groups of 4 (128x128 tiles held to 168 registers) or 2 (128x256 non-blend) */ \
+    constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? 2 : 4))); \
     constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
     const bool ep_fetch = EP_PF && p.res.p != nullptr; \
-    const int ep_rshift = 0; \
+    const int ep_rshift = (MODE == MODE_SPADE) ? p.res_shift : 0; \
 _Pragma("unroll") \
     for (int pg = 0; pg < EP_WPX; pg += EP_G) { \
-    f4_t ep_raw32[EP_G][EP_NCI]; h4_t ep_raw16[EP_G][EP_NCI]; float ep_ps[EP_G]; \
+    ep_u4_t ep_raw[EP_G][EP_NCI]; float ep_ps[EP_G]; \
     if (EP_PF && (ep_fetch || p.pixscale)) { \
 _Pragma("unroll") \
         for (int g = 0; g < EP_G; ++g) { \
@@ -96,15 +114,20 @@ _Pragma("unroll") \
                     if (cb >= p.Cout) continue; \
                     const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> ep_rshift) * p.res.sH + \
                                     (long)(w >> ep_rshift) * p.res.sW + cb; \
-                    if (p.res_f32) ep_raw32[g][(EP_PF ? ci / CSTEP : 0)] = *(const f4_t*)((const float*)p.res.p + xo); \
-                    else ep_raw16[g][(EP_PF ? ci / CSTEP : 0)] = *(const h4_t*)((const half_t*)p.res.p + xo); \
+                    if (p.res_f32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + xo); \
+                    else { \
+                        const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + xo); \
+                        ep_raw[g][(EP_PF ? ci / CSTEP : 0)][0] = q2[0]; ep_raw[g][(EP_PF ? ci / CSTEP : 0)][1] = q2[1]; \
+                    } \
                 } \
             } \
         } \
     } \
+    if (pg == 0) EP_TL(6); \
 _Pragma("unroll") \
     for (int g = 0; g < EP_G; ++g) { \
         const int pi = pg + g; \
+        if (pi == 1) EP_TL(7); \
         int m = ep_wpx * EP_WPX * 16 + pi * 16 + l15; \
         const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
         const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
@@ -118,28 +141,43 @@ _Pragma("unroll") \
             const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
             const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
             if (cb >= p.Cout) continue; \
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};     /* residual (STD / TBLEND) or the modulated tensor x (SPADE) */ \
+            if (p.res.p) { \
+                if (EP_PF) { \
+                    const ep_u4_t q4 = ep_raw[g][(EP_PF ? ci / CSTEP : 0)]; \
+                    if (p.res_f32) { \
+                        const f4_t qf = __builtin_bit_cast(f4_t, q4);     /* whole-vector cast: bit_cast of q4[r] reads element 0 */ \
+_Pragma("unroll") \
+                        for (int r = 0; r < 4; ++r) rr[r] = qf[r]; \
+                    } else { \
+                        ep_u2_t q2; q2[0] = q4[0]; q2[1] = q4[1]; \
+                        const h4_t hx = __builtin_bit_cast(h4_t, q2); \
+_Pragma("unroll") \
+                        for (int r = 0; r < 4; ++r) rr[r] = (float)hx[r]; \
+                    } \
+                } else { \
+                    load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> ep_rshift) * p.res.sH + \
+                                            (long)(w >> ep_rshift) * p.res.sW + cb, rr); \
+                } \
+            } \
             float v[4]; \
             if (MODE == MODE_TBLEND) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) \
                     v[r] = ps * (ep_acc[ci + CSTEP - 1][pi][r] + ((const float*)&ep_bias[ci])[r]) + (1.f - ps) * ep_acc[ci][pi][r]; \
             } else if (MODE == MODE_SPADE) { \
-                float x[4]; \
-                const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> p.res_shift) * p.res.sH + \
-                                (long)(w >> p.res_shift) * p.res.sW + cb; \
-                load4(p.res, p.res_f32, xo, x); \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
-                    const float g = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
-                    const float b = ep_acc[ci + CSTEP - 1][pi][r] + ((const float*)&ep_bias2[ci])[r]; \
-                    v[r] = (x[r] - ((const float*)&ep_mean[ci])[r]) * ((const float*)&ep_rstd[ci])[r] * (1.f + g) + b; \
+                    const float gm = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
+                    const float bt = ep_acc[ci + CSTEP - 1][pi][r] + ((const float*)&ep_bias2[ci])[r]; \
+                    v[r] = (rr[r] - ((const float*)&ep_mean[ci])[r]) * ((const float*)&ep_rstd[ci])[r] * (1.f + gm) + bt; \
                 } \
             } else { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
             } \
 _Pragma("unroll") \
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act0, p.slope0); \
+            for (int r = 0; r < 4; ++r) v[r] = EP_HEAVY ? apply_act(v[r], p.act0, p.slope0) : lin_act(v[r], ep_sl0); \
             if (MODE == MODE_PIXSHUF) { \
                 const int c = cb >> 2; \
                 if (c < 3) { \
@@ -152,15 +190,8 @@ _Pragma("unroll") \
                 continue; \
             } \
             if (MODE != MODE_SPADE && p.res.p) { \
-                if (EP_PF) { \
 _Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) v[r] += p.res_f32 ? ep_raw32[g][(EP_PF ? ci / CSTEP : 0)][r] : (float)ep_raw16[g][(EP_PF ? ci / CSTEP : 0)][r]; \
-                } else { \
-                    float rr[4]; \
-                    load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)h * p.res.sH + (long)w * p.res.sW + cb, rr); \
-_Pragma("unroll") \
-                    for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
-                } \
+                for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
             } \
             if ((MODE == MODE_STD || MODE == MODE_STDSTAT) && p.pixscale) { \
 _Pragma("unroll") \
@@ -180,7 +211,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
                     const float a = v[r] * ((const float*)&ep_s2[ci])[r] + ((const float*)&ep_t2[ci])[r]; \
-                    u[r] = apply_act(a, p.act1, p.slope1); \
+                    u[r] = lin_act(a, ep_sl1); \
                 } \
                 store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u); \
             } \
@@ -190,7 +221,7 @@ _Pragma("unroll") \
     if (EP_STAT) { /* fixed-order butterfly over the 16 position lanes, then one partial per (tile, wave, channel) */ \
         const int ep_tiles = p.nTW * p.nTH * p.nTD; \
         const int ep_nblk = ep_tiles * (BM / (EP_WPX * 16)); \
-        const int ep_blk = (blockIdx.x % ep_tiles) * (BM / (EP_WPX * 16)) + ep_wpx; \
+        const int ep_blk = (tile_lin % ep_tiles) * (BM / (EP_WPX * 16)) + ep_wpx; \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
             const int pb = (n0 + wch * WCH * 16) / 16 + ci; \

@@ -1,0 +1,506 @@
+// Convolution with LDS-staged input patches for gfx950 (CDNA4).
+//
+// Same GEMM view, packed-weight format and epilogues as conv_igemm.hip, different data movement:
+//   * activations: the (tile + kernel-1) input "halo" box of a CK-channel chunk is staged ONCE in LDS and every
+//     tap of the kernel reads its shifted window from there -- 9x (3x3), 27x (3x3x3) or 343x (7x7x7) fewer
+//     global/L2 reads, address computations and bounds checks than gathering a tile per tap;
+//   * weights: never touch LDS. The packed layout [kstep][Cout][32] makes one MFMA A-operand fragment
+//     (16 rows x 32 k) a contiguous 1 KiB, so each wave streams its own fragments global -> VGPR through a
+//     PFD-deep, statically indexed register ring (the loads of K-step s+PFD are issued right after step s has
+//     consumed its registers) -- deep enough to cover L2 / Infinity-Cache latency under load;
+//   * therefore no workgroup barrier inside the tap loop: one __syncthreads() per channel chunk (when the
+//     halo is swapped), waves otherwise run free and overlap each other's latencies;
+//   * SK variants (narrow Cout: the 7x7x7 mask conv): the 4 waves split the K-steps of every chunk instead of the
+//     positions, so each still issues 16 MFMAs per 8 LDS reads, and reduce their accumulators through LDS once.
+// Per K-step (32 channels of one tap) a wave issues WPX ds_read_b128 + WCH global_load_dwordx4 + WPX*WCH MFMAs.
+//
+// LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes.
+#pragma once
+#include "common.h"
+#ifdef CS_TIMELINE
+#define EP_TL(i) TL_STAMP(i)
+#endif
+#include "conv_epilogue.h"
+
+// Weight fragments are streamed with loads the compiler does not track (inline asm) and are waited for with an
+// explicit counted s_waitcnt: hipcc drains vmcnt to 0 at every loop back-edge for loads it tracks, which would
+// collapse the PFD-deep register ring to an effective depth of one K-step.
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void wfrag_load(u4_t& dst, const half_t* ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#ifdef CS_TIMELINE
+extern unsigned long long* g_cs_tl;
+extern long g_cs_tl_cap;
+// stamp i of this wave (lane 0 stores at the end); sched barriers keep the phases where they are written
+#define TL_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); tl_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TL_STAMP(i) do { } while (0)
+#endif
+
+// Static shapes (ST): the kernel extent and the position tile are compile-time constants, so the tap loop of a chunk is
+// fully unrolled: LDS window offsets become instruction immediates and all iterator arithmetic disappears.
+//   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
+//   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
+//   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
+//   ST 12 / 13: 3x2x2, tiles 4x4x16 and 8x8x2 (the hourglass up-blocks per output phase on the source grid)
+//   ST 10 / 11 / 14 / 15: 1x2x2, 1x2x1, 1x1x2, 1x1x1, tile 16x8 (the per-phase convs of mlp_shared on the up-sampled seg, run_G)
+template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
+template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<2> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 1; };
+template <> struct StaticShape<3> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 4; };
+template <> struct StaticShape<4> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 3, LH = 3, LD = 1; };
+template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 2, LH = 2, LD = 3; };
+template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
+template <> struct StaticShape<7> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 2; };   // 256 positions: 8x8x4
+template <> struct StaticShape<8> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 4; };   // 256 positions: 2x8x16
+template <> struct StaticShape<12> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 4; };
+template <> struct StaticShape<13> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 3, LH = 3, LD = 1; };
+template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 2, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 2, KW = 1, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<14> { static constexpr int KD = 1, KH = 1, KW = 2, LW = 4, LH = 3, LD = 0; };
+template <> struct StaticShape<15> { static constexpr int KD = 1, KH = 1, KW = 1, LW = 4, LH = 3, LD = 0; };
+
+template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
+// Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
+// unrolled 128x128 tiles (<= 168 VGPRs, no scratch) -- for short-K convs a third workgroup hides the prologue / epilogue
+// of the other two (gamma/beta convs K = 9 x 128: +15 % over the 128x256 tile, tools/ab_conv.sh); the dynamic-shape
+// variants would spill at that budget and stay unconstrained.
+__global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 && !SK && ST != 0) ? 3 : 1))) conv_halo_kernel(const ConvParams p)
+{
+    using SS = StaticShape<ST>;
+    static_assert(ST == 0 || !SK, "static shapes are not combined with split-K");
+    constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP;
+    constexpr int BN = WCH * 16 * WVC;
+    constexpr int SL = CK / 8;           // 16-byte slots per voxel
+    constexpr int SLP = SL + 1;          // ... plus one pad slot (bank spreading; also fetched, from the zero page)
+    constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
+    // halo pieces per thread whose source offsets are kept in registers (the big halos of the mask conv / 4x4x16 tiles too)
+    constexpr int HI = ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8) ? 13 : (ST == 12 ? 9 : 8));
+    constexpr int KH32 = CK / 32;        // 32-channel K-steps per tap and chunk
+    constexpr int PFD = 4;               // weight prefetch depth in K-steps
+    constexpr int SKS = SK ? 4 : 1;      // K-step stride of one wave
+    static_assert(WVP * WVC == 4, "4 waves per workgroup");
+    static_assert(!SK || (WVC == 1 && WPX == 8), "split-K variants: every wave covers all 128 positions");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef CS_TIMELINE
+    unsigned long long tl_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl_real0 = __builtin_amdgcn_s_memrealtime();     // constant 100 MHz clock
+    TL_STAMP(0);
+#endif
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpx = SK ? 0 : wave % WVP, wch = SK ? 0 : wave / WVP;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // position tile / channel block of this workgroup (ConvParams::xcd_map)
+    int tile_lin = blockIdx.x, cblk = blockIdx.y;
+    if (p.xcd_map != 0) {
+        const int flat = p.xcd_map == 2;
+        const int ncb = p.Cout_pad / BN;
+        const int total = (int)gridDim.x;                               // mode 1: tiles; mode 2: tiles x channel blocks
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int u = xcd * q + (xcd < r ? xcd : r) + i;                // bijection: XCD x owns q + (x < r) consecutive entries
+        if (flat) { tile_lin = u / ncb; cblk = u - tile_lin * ncb; }
+        else tile_lin = u;
+    }
+    int t = tile_lin;
+    const int tw = t % p.nTW; t /= p.nTW;
+    const int th = t % p.nTH; t /= p.nTH;
+    const int td = t % p.nTD; t /= p.nTD;
+    const int tn = t;
+    const int n0 = cblk * BN;
+    const int lgTW = ST ? SS::LW : p.lgTW, lgTH = ST ? SS::LH : p.lgTH, lgTD = ST ? SS::LD : p.lgTD;
+    const int KD = ST ? SS::KD : p.KD, KH = ST ? SS::KH : p.KH, KW = ST ? SS::KW : p.KW;
+    const int lgS = lgTW + lgTH + lgTD;
+    const int mW = (1 << lgTW) - 1, mH = (1 << lgTH) - 1, mD = (1 << lgTD) - 1;
+    const int TN = BM >> lgS;
+    const int HW = (1 << lgTW) + KW - 1, HH = (1 << lgTH) + KH - 1, HD = (1 << lgTD) + KD - 1;
+    const int HV = TN * HD * HH * HW;
+    const int nitems = HV * SLP;
+    const int w0 = tw << lgTW, h0 = th << lgTH, d0 = td << lgTD, nb = tn * TN;
+    const int ntaps = KD * KH * KW;
+
+    // ---- halo staging, global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
+    // The LDS image is linear in the piece index q = voxel*SLP + slot (SLP = SL data slots + 1 pad slot), which is
+    // what the instruction requires (wave-uniform base + lane*16). Out-of-range / pad pieces read the zero page.
+    auto piece_off = [&](int q, bool& inb) -> long {      // element offset of piece q's voxel (without the channel part)
+        const int hv = q / SLP;
+        const int hw = hv % HW; int r = hv / HW;
+        const int hh = r % HH; r /= HH;
+        const int hd = r % HD;
+        const int hn = r / HD;
+        const int n = nb + hn, id = d0 + hd - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW;
+        inb = q < nitems && (q % SLP) < SL && n < p.N && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H &&
+              (unsigned)iw < (unsigned)p.W;
+        return (long)n * p.in_sN + (long)id * p.in_sD + (long)(ih >> p.up_shift) * p.in_sH + (long)(iw >> p.up_shift) * p.in_sW +
+               (q % SLP) * 8;
+    };
+    // few pieces per thread: keep their offsets in registers (always the case in double-buffered mode, see launcher)
+    const bool pre = DB || nitems <= 256 * HI;
+    int poff[HI];
+    unsigned pmask = 0;
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < HI; ++j) {
+            bool inb;
+            const long o = piece_off(tid + 256 * j, inb);
+            poff[j] = inb ? (int)o : 0;
+            pmask |= inb ? (1u << j) : 0u;
+        }
+    }
+    auto glds = [&](const half_t* src, int buf, int q_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (size_t)buf * HV * VS + (size_t)q_wave_base * 16),
+                                         16, 0, 0);
+    };
+    auto stage_halo = [&](int buf, int c0) {     // asynchronous: completion is awaited by the next __syncthreads()
+        // channel part of the source offset; grouped mode: chunk j -> group j / cg at stride in_sG
+        long coff = c0;
+        int climit = p.Cin - c0;                 // channels of this chunk that exist
+        if (CK == 32 && p.cg > 0) {
+            const int j = c0 >> 5;
+            coff = (long)(j / p.cg) * p.in_sG + (j % p.cg) * 32;
+            climit = p.cg_cin - (j % p.cg) * 32;
+        }
+        if (pre) {
+#pragma unroll
+            for (int j = 0; j < HI; ++j) {
+                const int q = tid + 256 * j;
+                if (q < nitems) {
+                    const bool ok = ((pmask >> j) & 1u) && ((q % SLP) * 8 < climit);
+                    glds(ok ? p.in + poff[j] + coff : p.zero, buf, 256 * j + wave * 64);
+                }
+            }
+        } else if constexpr (!DB) {
+            for (int q0 = 0; q0 < nitems; q0 += 256) {
+                const int q = q0 + tid;
+                if (q < nitems) {
+                    bool inb;
+                    const long o = piece_off(q, inb);
+                    const bool ok = inb && ((q % SLP) * 8 < climit);
+                    glds(ok ? p.in + o + coff : p.zero, buf, q0 + wave * 64);
+                }
+            }
+        }
+    };
+
+    // ---- per-lane constants of the MFMA operand fetches
+    int abase[WPX];                      // LDS byte offset of this lane's position in the un-shifted halo window
+#pragma unroll
+    for (int pi = 0; pi < WPX; ++pi) {
+        int m = wpx * WPX * 16 + pi * 16 + l15;
+        const int wl = m & mW; m >>= lgTW;
+        const int hl = m & mH; m >>= lgTH;
+        const int dl = m & mD; m >>= lgTD;
+        abase[pi] = (((m * HD + dl) * HH + hl) * HW + wl) * VS + l4 * 16;
+    }
+    // weights: fragment ci of K-step kidx = 1 KiB at wgt + (kidx*Cout_pad + n0 + wch*WCH*16 + ci*16)*32; lane = (row l15, k l4*8)
+    const half_t* wbase = p.wgt;
+    if (p.wslot) wbase += p.wofs[p.wslot[nb < p.N ? nb : p.N - 1]];         // per-sample weight set (uniform over the tile)
+    const half_t* wlane = wbase + ((long)(n0 + wch * WCH * 16) * 32 + l15 * 32 + l4 * 8);
+    const long wstep = (long)p.Cout_pad * 32;
+    const int nck = (p.Cin + CK - 1) / CK;
+    const int j0 = SK ? wave : 0;
+
+    f4_t acc[WCH][WPX];
+#pragma unroll
+    for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+        for (int pi = 0; pi < WPX; ++pi) acc[ci][pi] = (f4_t){0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (ST != 0) {
+        // ---------------- static shape: the K-steps of a chunk are fully unrolled
+        constexpr int NT = SS::KD * SS::KH * SS::KW, NS = NT * KH32;
+        constexpr int PFS = NS < 3 ? NS : 3;      // weight ring depth; the ring is re-primed at every chunk
+        constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
+        u4_t wr[PFS][WCH];
+        // In this fully unrolled body hipcc counts vmcnt / lgkmcnt exactly (the only conservative drain sits at the chunk
+        // loop's back-edge, next to the barrier), so the weight fragments are ordinary loads here.
+        auto wload_at = [&](u4_t (&dst)[WCH], int cc, int st) {          // st: compile-time after unrolling
+            const int ccl = cc < nck ? cc : nck - 1;
+            const half_t* src = wlane + (long)((ccl * KH32 + st % KH32) * NT + st / KH32) * wstep;
+#pragma unroll
+            for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const u4_t*)(src + ci * 512);
+        };
+        TL_STAMP(1);
+        stage_halo(0, 0);
+        __syncthreads();
+        TL_STAMP(2);
+        if (DB && nck > 1) stage_halo(1, CK);
+        for (int cc = 0; cc < nck; ++cc) {
+            // prime the ring with this chunk's first steps before waiting on the halo: both latencies overlap
+#pragma unroll
+            for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
+            if (cc > 0) {
+                if (DB) {
+                    __syncthreads();                       // chunk cc has landed in buffer cc&1; everyone left the other one
+                    if (cc + 1 < nck) stage_halo((cc + 1) & 1, (cc + 1) * CK);
+                } else {
+                    __syncthreads();
+                    stage_halo(0, cc * CK);
+                    __syncthreads();
+                }
+            }
+            const unsigned char* hb = smem + (size_t)(DB ? (cc & 1) : 0) * HV * VS;
+            // Software-pipelined operand fetch: the position fragments are split in two halves; while the MFMAs of one half
+            // run, the ds_reads of the other half (of this step or of the next one) are in flight, so no LDS round trip is
+            // exposed in steady state and no extra registers are needed.
+            constexpr int HA = WPX / 2;                    // fragments in the first half
+            auto toff_of = [&](int st) -> int {
+                const int tap = st / KH32, half = st % KH32;
+                return (((tap / (SS::KW * SS::KH)) * SHH + (tap / SS::KW) % SS::KH) * SHW + tap % SS::KW) * VS + half * 64;
+            };
+            h8_t afA[HA > 0 ? HA : 1], afB[WPX - HA];
+#pragma unroll
+            for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + abase[pi] + toff_of(0));
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int toff = toff_of(st);
+#pragma unroll
+                for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + abase[pi] + toff);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+                    for (int pi = 0; pi < HA; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afA[pi],
+                                                                             acc[ci][pi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NS) {
+#pragma unroll
+                    for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + abase[pi] + toff_of(st + 1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+                    for (int pi = HA; pi < WPX; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afB[pi - HA],
+                                                                             acc[ci][pi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + PFS < NS) wload_at(wr[st % PFS], cc, st + PFS);
+            }
+        }
+    } else {
+        // This wave's K-step sequence: for every chunk cc, "fine" steps j = j0, j0+SKS, ... < ntaps*nhalf(cc) with
+        // tap = j / nhalf, half = j % nhalf; packed weight index kidx = (cc*KH32 + half)*ntaps + tap. Two scalar iterators
+        // walk it: the producer (weight prefetch, PFD steps ahead) and the consumer.
+        auto chunk_nhalf = [&](int cc) -> int {
+            const int rem = p.nchunks - cc * KH32;
+            return rem < KH32 ? rem : KH32;
+        };
+        struct It { int cc, nh, tap, half; };
+        auto it_init = [&](It& it) {
+            it.cc = 0; it.nh = chunk_nhalf(0); it.tap = 0; it.half = j0;
+            while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+        };
+        auto it_chunk_done = [&](const It& it) -> bool { return it.tap >= ntaps; };
+        auto it_next_chunk = [&](It& it) {
+            ++it.cc; it.nh = it.cc < nck ? chunk_nhalf(it.cc) : 1; it.tap = 0; it.half = j0;
+            while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+        };
+        auto it_advance = [&](It& it) {
+            it.half += SKS;
+            while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
+        };
+        It P;                                // producer
+        it_init(P);
+        long last_off = 0;
+        auto wload = [&](u4_t (&dst)[WCH]) {
+            while (P.cc < nck && it_chunk_done(P)) it_next_chunk(P);
+            if (P.cc < nck) { last_off = (long)((P.cc * KH32 + P.half) * ntaps + P.tap) * wstep; it_advance(P); }
+            // past the end the last valid fragment is re-read (never consumed): every step issues exactly WCH loads, so the
+            // counted wait below is exact in steady state and conservative otherwise
+            const half_t* src = wlane + last_off;
+            wfrag_load<0>(dst[0], src);
+            if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
+            if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
+            if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
+            if constexpr (WCH > 4) wfrag_load<0>(dst[4], src + 2048);
+        };
+
+        u4_t wr[PFD][WCH];
+    #pragma unroll
+        for (int i = 0; i < PFD; ++i) wload(wr[i]);
+
+        TL_STAMP(1);
+        stage_halo(0, 0);
+        __syncthreads();
+        TL_STAMP(2);
+        if (DB && nck > 1) stage_halo(1, CK);
+        int cur = 0;
+        It C;                                // consumer
+        it_init(C);
+        // (kd, kh, kw) of C.tap, kept incrementally
+        int ckw = C.tap % KW, ckh = (C.tap / KW) % KH, ckd = C.tap / (KW * KH), ctap = C.tap;
+        const unsigned char* hb = smem;
+        bool done = false;
+        while (!done) {
+    #pragma unroll
+            for (int i = 0; i < PFD; ++i) {
+                while (!done && it_chunk_done(C)) {            // this wave finished its share of chunk C.cc
+                    if (C.cc + 1 >= nck) { done = true; break; }
+                    if (DB) {
+                        __syncthreads();                       // chunk cc+1 has landed in buffer cur^1; everyone left buffer cur
+                        if (C.cc + 2 < nck) stage_halo(cur, (C.cc + 2) * CK);
+                        cur ^= 1;
+                    } else {
+                        __syncthreads();                       // everyone is done reading the single buffer
+                        stage_halo(0, (C.cc + 1) * CK);
+                        __syncthreads();
+                    }
+                    it_next_chunk(C);
+                    ctap = C.tap; ckw = ctap % KW; ckh = (ctap / KW) % KH; ckd = ctap / (KW * KH);
+                    hb = smem + (size_t)cur * HV * VS;
+                }
+                if (done) break;
+                while (ctap < C.tap) { ++ctap; if (++ckw == KW) { ckw = 0; if (++ckh == KH) { ckh = 0; ++ckd; } } }
+                const int toff = ((ckd * HH + ckh) * HW + ckw) * VS + C.half * 64;
+                h8_t af[WPX];
+    #pragma unroll
+                for (int pi = 0; pi < WPX; ++pi) af[pi] = *(const h8_t*)(hb + abase[pi] + toff);
+                wait_vmcnt_le<WCH*(PFD - 1)>();               // the WCH loads of this step's slot are older than the last WCH*(PFD-1)
+                __builtin_amdgcn_sched_barrier(0);             // keep the MFMAs below the wait (hipcc would hoist them)
+    #pragma unroll
+                for (int ci = 0; ci < WCH; ++ci)
+    #pragma unroll
+                    for (int pi = 0; pi < WPX; ++pi)
+                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[i][ci]), af[pi], acc[ci][pi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);             // ... and the reload of the slot below its last reader
+                wload(wr[i]);
+                it_advance(C);
+            }
+        }
+    }
+
+    if constexpr (ST == 0) {
+        // The asm ring still has untracked loads in flight (re-reads issued by the last PFD steps): drain them before the
+        // compiler reuses those VGPRs in the epilogue.
+        wait_vmcnt_le<0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // sigmoid / GELU epilogues exist in: the pixel-shuffle kernel (conv_img), the 16-channel tiles (T's mask conv), the 1x1 kernels
+    // (the motion extractor's linear layers) and the dynamic-shape fallbacks (small maps of the same layers)
+    constexpr bool EP_HEAVY = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
+    TL_STAMP(3);
+    if constexpr (!SK) {
+        constexpr int EP_WPX = WPX;
+        const int ep_wpx = wpx;
+        auto& ep_acc = acc;
+        CONV_EPILOGUE()
+    } else {
+        // reduce the four waves' partial accumulators through LDS; wave w finishes position blocks 2w, 2w+1
+        __syncthreads();                                   // halo no longer needed: reuse it
+        float* red = (float*)smem;                         // [4 waves][WCH*WPX frags][4][64 lanes]
+#pragma unroll
+        for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+            for (int pi = 0; pi < WPX; ++pi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((wave * WCH * WPX + ci * WPX + pi) * 4 + r) * 64 + lane] = acc[ci][pi][r];
+        __syncthreads();
+        constexpr int EP_WPX = 2;
+        const int ep_wpx = wave;
+        f4_t ep_acc[WCH][EP_WPX];
+#pragma unroll
+        for (int ci = 0; ci < WCH; ++ci)
+#pragma unroll
+            for (int q = 0; q < EP_WPX; ++q) {
+                const int pi = wave * EP_WPX + q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) s += red[((w * WCH * WPX + ci * WPX + pi) * 4 + r) * 64 + lane];
+                    ep_acc[ci][q][r] = s;
+                }
+            }
+        CONV_EPILOGUE()
+    }
+#ifdef CS_TIMELINE
+    TL_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(5);
+    const unsigned long long tl_real5 = __builtin_amdgcn_s_memrealtime();
+    if (p.tl && lane == 0) {
+        const long wi = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave;
+        if (wi < p.tl_cap) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = p.tl + wi * 12;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = tl_t[i];
+            o[8] = tl_real0; o[9] = tl_real5; o[10] = hwid; o[11] = xcc;
+        }
+    }
+#endif
+}
+
+template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK, int ST>
+static int launch_halo_st(const ConvParams& p, hipStream_t st)
+{
+    constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP, BN = WCH * 16 * WVC;
+    constexpr int SLP = CK / 8 + 1, VS = SLP * 16;
+    if (p.Cout_pad % BN != 0) { cs_set_error("conv_halo: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
+    constexpr bool heavy_ok = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
+    if ((!heavy_ok && p.act0 >= ACT_SIGMOID) || p.act1 >= ACT_SIGMOID) {
+        cs_set_error("conv_halo: this tile configuration carries no sigmoid / GELU epilogue (act0 %d, act1 %d)", p.act0, p.act1);
+        return -1;
+    }
+    if (p.inD != p.D) { cs_set_error("conv_halo: depth-collapsing convs are not supported"); return -1; }
+    const int lgS = p.lgTW + p.lgTH + p.lgTD;
+    if ((1 << lgS) > BM) { cs_set_error("conv_halo: spatial tile exceeds BM"); return -1; }
+    if (MODE == MODE_SPADE && (1 << lgS) != BM) { cs_set_error("conv_halo: SPADE launches must tile within one sample"); return -1; }
+    if (p.wslot && (1 << lgS) != BM) { cs_set_error("conv_halo: per-sample weight sets need tiles within one sample"); return -1; }
+    const int TN = BM >> lgS;
+    const long HV = (long)TN * ((1 << p.lgTD) + p.KD - 1) * ((1 << p.lgTH) + p.KH - 1) * ((1 << p.lgTW) + p.KW - 1);
+    const int nck = (p.Cin + CK - 1) / CK;
+    // double-buffered halos: up to 64 KB per workgroup (two or three workgroups stay resident); the 256x160 tiles run one workgroup
+    // per CU and take what they need
+    constexpr bool big = (BM == 256 && WCH == 5);
+    const bool db = nck > 1 && 2 * HV * VS <= (big ? 128 : 64) * 1024 && HV * SLP <= 256 * (big ? 13 : 8);
+    size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
+    if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
+    if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
+    dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
+    if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1);
+    hipError_t e;
+#ifdef CS_TIMELINE
+    ConvParams kp = p; kp.tl = g_cs_tl; kp.tl_cap = g_cs_tl_cap;
+#else
+    const ConvParams& kp = p;
+#endif
+    if (db) {
+        auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, true, SK, ST>;
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { cs_set_error("conv_halo: opting into %zu bytes of LDS failed: %s", lds, hipGetErrorString(e)); return -1; }
+        }
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, kp);
+    } else {
+        auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, false, SK, ST>;
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { cs_set_error("conv_halo: opting into %zu bytes of LDS failed: %s", lds, hipGetErrorString(e)); return -1; }
+        }
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, st, kp);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { cs_set_error("conv_halo launch: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+

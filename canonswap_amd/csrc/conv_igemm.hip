@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
     const int wpx = wave % WVP, wch = wave / WVP;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    int t = blockIdx.x;
+    const int tile_lin = blockIdx.x;
+    int t = tile_lin;
     const int tw = t % p.nTW; t /= p.nTW;
     const int th = t % p.nTH; t /= p.nTH;
     const int td = t % p.nTD; t /= p.nTD;
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
     }
 
     constexpr int EP_WPX = WPX;
+    constexpr bool EP_HEAVY = true;      // the cross-check kernel carries every activation
     const int ep_wpx = wpx;
     auto& ep_acc = acc;
     CONV_EPILOGUE()
@@ -163,6 +165,8 @@ static int launch_cfg(const ConvParams& p, hipStream_t st)
 
 int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st)
 {
+    if (p.wslot) { cs_set_error("conv_igemm: per-sample weight sets are only implemented by conv_halo"); return -1; }
+    if (p.act1 >= ACT_SIGMOID) { cs_set_error("conv_igemm: the second output takes none / ReLU / LeakyReLU only"); return -1; }
     if (mode == MODE_STD && p.stat_out) {
         switch (cfg) {
         case CFG_128x128: return launch_cfg<4, 4, 2, 2, MODE_STDSTAT>(p, st);

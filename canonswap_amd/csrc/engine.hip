@@ -44,13 +44,21 @@ struct ConvL {            // one packed convolution layer
 
 struct Affine { const float* s = nullptr; const float* t = nullptr; };
 
-struct TLayer { ConvL fused; ConvL mask; const float* raw; const float* fc; const float* bias; half_t* wmut; };
+constexpr int MAX_SLOTS = CS_MAX_IDENTITY_SLOTS;
+// wset[s]: the fused [W; w_mod] packed weights of identity slot s (slot 0 lives in the uploaded blob, the others are allocated on
+// first use); wofs: element offsets wset[s] - wset[0] in device memory for launches that mix identities
+struct TLayer { ConvL fused; ConvL mask; const float* raw; const float* fc; const float* bias; half_t* wset[MAX_SLOTS]; long* wofs; };
 
 }  // namespace
 
 struct cs_engine {
     int dev = 0, maxB = 1;
-    bool finalized = false, identity_set = false;
+    bool finalized = false;
+    bool slot_set[MAX_SLOTS] = {};
+    int* slot_dev = nullptr;               // per-sample identity slot of the current batch (device)
+    int* slot_pin = nullptr;               // pinned staging ring for slot_dev uploads
+    int slot_ring = 0;
+    std::vector<int> slot_cur;             // what slot_dev holds
     std::map<std::string, Blob> blobs;
     std::vector<void*> allocs;
 
@@ -241,6 +249,13 @@ int pick_cfg(int Cout_pad)
 // tiles measured slower (more halo re-reads than the extra occupancy returns)
 int cfg_v32() { return CFG_H_256x32; }
 
+// ConvParams::xcd_map of every engine launch (A/B knob CANONSWAP_XCD_MAP=0|1|2)
+int xcd_map_default()
+{
+    static const int v = [] { const char* s = getenv("CANONSWAP_XCD_MAP"); return s ? atoi(s) : 2; }();   // 2: +0.8 % on the step (r02 A/B)
+    return v;
+}
+
 bool halo_enabled()
 {
     static const bool on = getenv("CANONSWAP_NO_HALO") == nullptr;
@@ -269,7 +284,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     e->flops += fl;
     if (halo_enabled() && c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
-        const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16) ? 256 : 128;
+        const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160) ? 256 : 128;
         const bool is3d = c.p.KD > 1;
         if (!prefW) { prefW = is3d ? 8 : 16; prefH = is3d ? 8 : BM / 16; }
         set_tile(c.p, BM, prefW, prefH);
@@ -280,6 +295,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (BM / wave_px);
         }
         const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0) ? 64 : 32;
+        c.p.xcd_map = xcd_map_default();
         return e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl);
     }
     if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
@@ -413,11 +429,14 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     }
     ConvCall t = mk(e->w_tail, e->dm_l[0], dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // util.py:261-263
     t.p.act0 = ACT_RELU; t.p.out0 = dhwc(e->dm_pred, FD, 64, 64, 144);
-    t.hcfg = CFG_H_128x160;
+    // 160-wide tiles: 128 positions (two workgroups per CU) or 256 positions (one per CU, half the weight bytes per MFMA)
+    // (tail 1.78 -> 1.29 ms, mask 2.63 -> 2.01 ms per 16 frames, profiles/r02_timeline_*.txt; CANONSWAP_TILE256x160=0 is the A/B knob)
+    static const bool big160 = [] { const char* s = getenv("CANONSWAP_TILE256x160"); return s ? atoi(s) != 0 : true; }();
+    t.hcfg = big160 ? CFG_H_256x160 : CFG_H_128x160;
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
-    m.hcfg = CFG_H_128x160;
+    m.hcfg = big160 ? CFG_H_256x160 : CFG_H_128x160;
     {   // no halo along W (KW = 1): a 2x8x8 tile stages 392 halo voxels per 128 positions, 8x8x2 would stage 896
         static const bool wide = getenv("CANONSWAP_MASK_TILE8") != nullptr;
         TRY(go(e, m, st, wide ? 8 : 2, 8));
@@ -456,9 +475,24 @@ int run_warp_out(cs_engine* e, int B, const half_t* vol16, const float* occ, hip
 // ------------------------------------------------------------------------------------------------ T
 // transfer_model2.forward (adaptive_modulate.py:522-554). x: fp32 vs[*cur] + fp16 copy va[0].
 // On exit: fp32 result in vs[*cur], fp16 copy in va[0].
-int run_T(cs_engine* e, int B, int* cur, hipStream_t st)
+// slots: B host ints (identity slot per sample)
+int run_T(cs_engine* e, int B, const int* slots, int* cur, hipStream_t st)
 {
-    if (!e->identity_set) { cs_set_error("cs_swap: cs_set_identity has not been called"); return -1; }
+    bool mixed = false;
+    for (int b = 0; b < B; ++b) {
+        if (slots[b] < 0 || slots[b] >= MAX_SLOTS) { cs_set_error("cs_swap: identity slot %d outside [0, %d)", slots[b], MAX_SLOTS); return -1; }
+        if (!e->slot_set[slots[b]]) { cs_set_error("cs_swap: cs_set_identity has not been called for slot %d", slots[b]); return -1; }
+        mixed |= slots[b] != slots[0];
+    }
+    if (mixed) {    // upload the per-sample slot vector when it changed (pinned ring: earlier async copies may still be pending)
+        if (e->slot_cur.size() != (size_t)B || memcmp(e->slot_cur.data(), slots, sizeof(int) * B) != 0) {
+            int* stage = e->slot_pin + (size_t)(e->slot_ring++ % 16) * e->maxB;
+            memcpy(stage, slots, sizeof(int) * B);
+            hipError_t r = hipMemcpyAsync(e->slot_dev, stage, sizeof(int) * B, hipMemcpyHostToDevice, st);
+            if (r != hipSuccess) { cs_set_error("slot upload: %s", hipGetErrorString(r)); return -1; }
+            e->slot_cur.assign(slots, slots + B);
+        }
+    }
     for (int i = 0; i < 7; ++i) {
         for (int j = 0; j < 2; ++j) {   // ResnetBlock_Adaptive2D: conv1 -> ReLU -> conv2, + x (:337-349)
             TLayer& L = e->t_l[i * 2 + j];
@@ -469,6 +503,8 @@ int run_T(cs_engine* e, int B, int* cur, hipStream_t st)
             TRY(go(e, mc, st));
             ConvCall fc = mk(L.fused, in, hwdc2(nullptr), B, 1, 64, 64);      // [W ; w_mod] fused, blend epilogue
             fc.mode = MODE_TBLEND;
+            if (mixed) { fc.p.wgt = L.wset[0]; fc.p.wofs = L.wofs; fc.p.wslot = e->slot_dev; }   // per-sample w_mod (groups=N, :157-167)
+            else fc.p.wgt = L.wset[slots[0]];
             fc.p.Cout = 512;
             fc.p.bias = L.bias;
             fc.p.pixscale = e->tmask; fc.p.ps_stride = 4;
@@ -649,6 +685,15 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     return go(e, ci, st);
 }
 
+// Every entry point runs with the engine's device current and restores the caller's device on exit (the engine may be driven
+// from a thread whose current device is another GPU).
+struct DevGuard {
+    int prev = -1, dev;
+    explicit DevGuard(int d) : dev(d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) hipSetDevice(dev); }
+    ~DevGuard() { if (prev >= 0 && prev != dev) hipSetDevice(prev); }
+};
+#define ENTER(e, B) TRY(check(e, B)); DevGuard dev_guard_((e)->dev)
+
 int check(cs_engine* e, int B)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
@@ -724,7 +769,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
         cs_set_error("cs_create: HIP device %d not available (%d devices visible)", device_id, ndev);
         return -1;
     }
-    CS_CHECK_HIP(hipSetDevice(device_id));
+    DevGuard guard(device_id);
     cs_engine* e = new cs_engine();
     e->dev = device_id; e->maxB = max_batch;
     const size_t B = (size_t)max_batch;
@@ -740,6 +785,8 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     A(kpbuf, B * 21 * 3 * 2);
     A(w_t3, B * 4096 * 256); A(seg16, B * 4096 * 256);
     A(tmask, B * 4096 * 4); A(style, 14 * 512);
+    A(slot_dev, B);
+    CS_CHECK_HIP(hipHostMalloc((void**)&e->slot_pin, sizeof(int) * 16 * B));
     e->stats_slots = 48; e->stats_slot_floats = B * 512 * 2;
     A(stats_pool, e->stats_slots * e->stats_slot_floats);
     A(stats_part, B * 262144); A(dm_occpart, B * 4096 * 16);
@@ -762,9 +809,10 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
 extern "C" void cs_destroy(cs_engine* e)
 {
     if (!e) return;
-    hipSetDevice(e->dev);
+    DevGuard guard(e->dev);
     hipDeviceSynchronize();
     for (void* p : e->allocs) hipFree(p);
+    if (e->slot_pin) hipHostFree(e->slot_pin);
     for (auto& kv : e->blobs) hipFree(kv.second.p);
     for (hipEvent_t ev : e->evpool) hipEventDestroy(ev);
     delete e;
@@ -773,7 +821,7 @@ extern "C" void cs_destroy(cs_engine* e)
 extern "C" int cs_upload(cs_engine* e, const char* name, const void* host_ptr, size_t nbytes)
 {
     if (!e || !name || !host_ptr || !nbytes) { cs_set_error("cs_upload: bad arguments"); return -1; }
-    CS_CHECK_HIP(hipSetDevice(e->dev));
+    DevGuard guard(e->dev);
     Blob& b = e->blobs[name];
     if (b.p) { hipFree(b.p); b.p = nullptr; }
     CS_CHECK_HIP(hipMalloc(&b.p, nbytes));
@@ -786,6 +834,7 @@ extern "C" int cs_upload(cs_engine* e, const char* name, const void* host_ptr, s
 extern "C" int cs_finalize_weights(cs_engine* e)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
+    DevGuard guard(e->dev);
     char n[96];
     // ---- M (optional)
     e->has_m = e->find("M.stem.w") != nullptr;
@@ -861,7 +910,11 @@ extern "C" int cs_finalize_weights(cs_engine* e)
         snprintf(n, sizeof n, "T.b%d.c%d", i / 2, i % 2 + 1);
         std::string base = n;
         TRY(get_conv(e, base, 512, 1024, 512, 1, 3, 3, 0, 2.0 * 512 * 512 * 9, &L.fused));
-        L.wmut = (half_t*)L.fused.w;
+        L.wset[0] = (half_t*)L.fused.w;
+        if (!L.wofs) { TRY(e->alloc(&L.wofs, (size_t)MAX_SLOTS)); }
+        long ofs[MAX_SLOTS];
+        for (int sl = 0; sl < MAX_SLOTS; ++sl) ofs[sl] = L.wset[sl] ? (long)(L.wset[sl] - L.wset[0]) : 0;
+        CS_CHECK_HIP(hipMemcpy(L.wofs, ofs, sizeof(ofs), hipMemcpyHostToDevice));
         TRY(get_conv(e, base + ".mask", 512, 16, 4, 1, 3, 3, 4, 512.0 * 1 * 9, &L.mask));
         TRY(get_f32(e, base + ".raw", 512 * 9 * 512, &L.raw));
         TRY(get_f32(e, base + ".fc", 2 * (512 * 512 + 512), &L.fc));
@@ -933,6 +986,7 @@ extern "C" int cs_finalize_weights(cs_engine* e)
         }
     }
     TRY(get_conv(e, "G.img", 64, 16, 16, 1, 3, 3, 16, 64.0 * 12 * 9, &e->g_img));
+    for (int sl = 0; sl < MAX_SLOTS; ++sl) e->slot_set[sl] = false;      // modulated weights derive from the (new) raw weights
     e->finalized = true;
     return 0;
 }
@@ -940,21 +994,30 @@ extern "C" int cs_finalize_weights(cs_engine* e)
 extern "C" int cs_set_identity(cs_engine* e, int slot, const float* id, void* stream)
 {
     if (!e || !e->finalized) { cs_set_error("cs_set_identity: engine not finalized"); return -1; }
-    if (slot != 0) { cs_set_error("cs_set_identity: only slot 0 is available"); return -1; }
+    if (slot < 0 || slot >= MAX_SLOTS) { cs_set_error("cs_set_identity: slot %d outside [0, %d)", slot, MAX_SLOTS); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    CS_CHECK_HIP(hipSetDevice(e->dev));
+    DevGuard guard(e->dev);
+    const size_t fused_elems = (size_t)(512 / 32) * 9 * 1024 * 32;       // packed [kstep][1024 rows][32]
     for (int i = 0; i < 14; ++i) {
         TLayer& L = e->t_l[i];
+        if (!L.wset[slot]) {     // first use of this slot: own copy of the fused buffer (the shared W rows never change)
+            half_t* w = nullptr;
+            TRY(e->alloc(&w, fused_elems));
+            TRY(copy_dd(w, L.wset[0], fused_elems * sizeof(half_t), st));
+            L.wset[slot] = w;
+            const long ofs = w - L.wset[0];
+            CS_CHECK_HIP(hipMemcpy(L.wofs + slot, &ofs, sizeof(long), hipMemcpyHostToDevice));
+        }
         TRY(e->run(1, st, [&] { return launch_t_style(id, L.fc, e->style + i * 512, 1, st); }, "t_style"));
-        TRY(e->run(1, st, [&] { return launch_t_modulate(L.raw, e->style + i * 512, L.wmut, i, st); }, "t_modulate"));
+        TRY(e->run(1, st, [&] { return launch_t_modulate(L.raw, e->style + i * 512, L.wset[slot], i, st); }, "t_modulate"));
     }
-    e->identity_set = true;
+    e->slot_set[slot] = true;
     return 0;
 }
 
 extern "C" int cs_extract_feature_3d(cs_engine* e, int B, const float* img, float* f_out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     int cur = 0;
     TRY(run_F(e, B, img, &cur, st));
@@ -964,7 +1027,7 @@ extern "C" int cs_extract_feature_3d(cs_engine* e, int B, const float* img, floa
 extern "C" int cs_warp(cs_engine* e, int B, const float* f, const float* kp_source, const float* kp_driving, float* f_out,
                        float* occ_out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
     TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
@@ -976,27 +1039,34 @@ extern "C" int cs_warp(cs_engine* e, int B, const float* f, const float* kp_sour
 
 extern "C" int cs_warp_out(cs_engine* e, int B, const float* f, const float* occ, float* seg_out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, nullptr, e->va[0], st));
     TRY(run_warp_out(e, B, e->va[0], occ, st));
     return e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }, "nhwc16_to_nchw");
 }
 
-extern "C" int cs_swap(cs_engine* e, int slot, int B, const float* f, float* f_out, void* stream)
+extern "C" int cs_swap_ids(cs_engine* e, const int* slots, int B, const float* f, float* f_out, void* stream)
 {
-    TRY(check(e, B));
-    if (slot != 0) { cs_set_error("cs_swap: only slot 0 is available"); return -1; }
+    ENTER(e, B);
+    if (!slots) { cs_set_error("cs_swap_ids: null slot vector"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     int cur = 0;
     TRY(to_hwdc(e, B, f, e->vs[0], e->va[0], st));
-    TRY(run_T(e, B, &cur, st));
+    TRY(run_T(e, B, slots, &cur, st));
     return from_hwdc(e, B, e->vs[cur], f_out, st);
+}
+
+extern "C" int cs_swap(cs_engine* e, int slot, int B, const float* f, float* f_out, void* stream)
+{
+    if (B < 1) { cs_set_error("batch %d", B); return -1; }
+    std::vector<int> slots((size_t)B, slot);
+    return cs_swap_ids(e, slots.data(), B, f, f_out, stream);
 }
 
 extern "C" int cs_refine(cs_engine* e, int B, const float* f, float* f_out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     int cur = 0;
     TRY(to_hwdc(e, B, f, e->vs[0], e->va[0], st));
@@ -1007,7 +1077,7 @@ extern "C" int cs_refine(cs_engine* e, int B, const float* f, float* f_out, void
 extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float* kp_driving, const float* kp_source,
                                float* occ_out, float* deformation_out, float* seg_out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
     TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
@@ -1021,7 +1091,7 @@ extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float*
 
 extern "C" int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img_out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(e->run(1, st, [&] { return launch_nchw_to_nhwc16(seg, e->seg16, B, 256, 4096, st); }, "nchw_to_nhwc16"));
     return run_G(e, B, e->seg16, img_out, st);
@@ -1029,13 +1099,14 @@ extern "C" int cs_spade_decode(cs_engine* e, int B, const float* seg, float* img
 
 extern "C" int cs_motion_extract(cs_engine* e, int B, const float* img, float* out, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     return run_M(e, B, img, out, (hipStream_t)stream);
 }
 
 extern "C" int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, int H, int W, void* stream)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
+    DevGuard guard(e->dev);
     hipStream_t st = (hipStream_t)stream;
     return e->run(1, st, [&] { return launch_pack_u8(img, out, B, 3, H, W, st); }, "pack_u8");
 }
@@ -1043,6 +1114,7 @@ extern "C" int cs_pack_u8(cs_engine* e, int B, const float* img, uint8_t* out, i
 extern "C" int cs_unpack_u8(cs_engine* e, int B, const uint8_t* img, float* out, int H, int W, void* stream)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
+    DevGuard guard(e->dev);
     hipStream_t st = (hipStream_t)stream;
     return e->run(1, st, [&] { return launch_unpack_u8(img, out, B, 3, H, W, st); }, "unpack_u8");
 }
@@ -1050,8 +1122,16 @@ extern "C" int cs_unpack_u8(cs_engine* e, int B, const uint8_t* img, float* out,
 extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
                               float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream)
 {
-    TRY(check(e, B));
-    if (slot != 0) { cs_set_error("cs_swap_frames: only slot 0 is available"); return -1; }
+    if (B < 1) { cs_set_error("batch %d", B); return -1; }
+    std::vector<int> slots((size_t)B, slot);
+    return cs_swap_frames_ids(e, slots.data(), B, img, x_t, x_can, out_f32, out_u8, rec_can, swap_can, stream);
+}
+
+extern "C" int cs_swap_frames_ids(cs_engine* e, const int* slots, int B, const float* img, const float* x_t, const float* x_can,
+                                  float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream)
+{
+    ENTER(e, B);
+    if (!slots) { cs_set_error("cs_swap_frames_ids: null slot vector"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     int cur = 0;
     TRY(run_F(e, B, img, &cur, st));                                                      // :242 f_s
@@ -1067,7 +1147,7 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
         TRY(run_warp_out(e, B, e->va[0], occ1, st));
         TRY(run_G(e, B, e->seg16, rec_can, st));
     }
-    TRY(run_T(e, B, &cur, st));                                                             // :253
+    TRY(run_T(e, B, slots, &cur, st));                                                      // :253
     if (swap_can) {                                                                         // :257
         TRY(run_warp_out(e, B, e->va[0], occ1, st));
         TRY(run_G(e, B, e->seg16, swap_can, st));
@@ -1088,7 +1168,7 @@ extern "C" int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, c
 extern "C" int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, const float* kp_source, int ns, const float* kp_driving,
                                  float* out_f32, uint8_t* out_u8, void* stream)
 {
-    TRY(check(e, B));
+    ENTER(e, B);
     if ((nf != 1 && nf != B) || (ns != 1 && ns != B)) { cs_set_error("cs_animate_frames: nf / ns must be 1 or B"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, nf, f, e->vs[0], nullptr, st));
@@ -1154,10 +1234,11 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     c.mode = d->mode;
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo
         const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p, c.mode);
-        const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16) ? 256 : 128;
+        const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160) ? 256 : 128;
         const bool is3d = p.KD > 1;
         set_tile(p, BM, d->tile_w ? d->tile_w : (is3d ? 8 : 16), d->tile_h ? d->tile_h : (is3d ? 8 : BM / 16));
         const int ck = d->ck ? d->ck : ((!is3d && p.Cin % 64 == 0) ? 64 : 32);
+        p.xcd_map = d->xcd_map > 0 ? d->xcd_map - 1 : xcd_map_default();
         return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);
     }
     c.cfg = d->cfg >= 0 ? d->cfg : pick_cfg(p.Cout_pad);

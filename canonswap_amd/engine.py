@@ -30,7 +30,8 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.lib.cs_create(device_id, max_batch, C.byref(h)), "cs_create")
         self.h = h
-        self._id_key = None
+        self._ids = []            # resident identities: [slot, device copy (512,), last tensor seen, its _version, use tick]
+        self._tick = 0
 
     def close(self):
         if getattr(self, "h", None):
@@ -51,7 +52,7 @@ class Engine:
             arr = np.ascontiguousarray(arr)
             _lib.check(self.lib.cs_upload(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.nbytes), f"cs_upload({name})")
         _lib.check(self.lib.cs_finalize_weights(self.h), "cs_finalize_weights")
-        self._id_key = None
+        self._ids = []
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -77,20 +78,79 @@ class Engine:
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def _out(self, t, shape, dtype):
+        """A caller-provided output buffer must be exactly what the C ABI will write: device, dtype, shape, contiguous."""
+        if t is None:
+            return self._new(*shape, dtype=dtype)
+        if not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != dtype or tuple(t.shape) != tuple(shape) \
+                or not t.is_contiguous():
+            raise ValueError(f"output buffer must be a contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}")
+        return t
+
     def set_identity(self, source_id: torch.Tensor, slot: int = 0):
-        """Per-identity precompute of T's modulated weights (adaptive_modulate.py:148-155). source_id: (1,512) or (512,)."""
+        """Per-identity precompute of T's modulated weights (adaptive_modulate.py:148-155) into an identity slot.
+        source_id: (1,512) or (512,)."""
         sid = source_id.detach().to(self.device).float().reshape(-1, 512)
-        if sid.shape[0] != 1 and not bool((sid == sid[:1]).all()):
-            raise ValueError("one identity per slot: all rows of source_id must be equal")
-        sid = sid[0].contiguous()
-        _lib.check(self.lib.cs_set_identity(self.h, slot, _ptr(sid), self._stream()), "cs_set_identity")
-        self._keep = sid
+        if sid.shape[0] != 1:
+            raise ValueError("set_identity takes one identity; pass several rows to swap()/swap_frames() instead")
+        sid = sid[0].contiguous().clone()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cs_set_identity(self.h, slot, _ptr(sid), self._stream()), "cs_set_identity")
+        self._ids = [r for r in self._ids if r[0] != slot]
+        self._tick += 1
+        self._ids.append([slot, sid, None, None, self._tick])
+        return slot
+
+    def _slot_of_row(self, row: torch.Tensor, src=None):
+        """Slot that holds identity `row` (512 floats on the device), computing it into the least recently used slot if needed.
+        Identities are compared by VALUE (2 KB), never by address: the allocator reuses addresses of freed tensors."""
+        self._tick += 1
+        for r in self._ids:
+            if torch.equal(r[1], row):
+                r[4] = self._tick
+                return r[0]
+        used = {r[0] for r in self._ids}
+        free = [k for k in range(_lib.MAX_IDENTITY_SLOTS) if k not in used]
+        slot = free[0] if free else min(self._ids, key=lambda r: r[4])[0]
+        return self.set_identity(row, slot)
+
+    def identity_slots(self, source_id: torch.Tensor, B: int):
+        """Per-sample identity slots for a (1,512), (512,) or (B,512) source_id (the reference's per-sample dlatents)."""
+        # fast path of the per-frame loop: the very same tensor object, unmodified since it was resolved (a strong reference
+        # is kept, so its address cannot have been recycled)
+        for r in self._ids:
+            if r[2] is source_id and r[3] == source_id._version and source_id.numel() == 512:
+                self._tick += 1
+                r[4] = self._tick
+                return [r[0]] * B
+        sid = source_id.detach().to(self.device).float().reshape(-1, 512)
+        if sid.shape[0] not in (1, B):
+            raise ValueError(f"source_id holds {sid.shape[0]} identities for a batch of {B}")
+        uniq, inv = torch.unique(sid, dim=0, return_inverse=True)
+        if uniq.shape[0] > _lib.MAX_IDENTITY_SLOTS:
+            raise ValueError(f"{uniq.shape[0]} distinct identities in one batch exceed the {_lib.MAX_IDENTITY_SLOTS} identity slots")
+        slot_of = [self._slot_of_row(uniq[k].contiguous()) for k in range(uniq.shape[0])]
+        if len(set(slot_of)) != len(slot_of):       # an eviction inside this very batch: cannot happen with <= MAX slots
+            raise RuntimeError("identity slot assignment collided")
+        slots = [slot_of[int(k)] for k in inv.tolist()]
+        if sid.shape[0] == 1:
+            slots = slots * B
+            for r in self._ids:
+                if r[0] == slots[0]:
+                    r[2], r[3] = source_id, source_id._version
+        return slots
 
     def ensure_identity(self, source_id: torch.Tensor):
-        key = (source_id.data_ptr(), source_id._version, tuple(source_id.shape))
-        if key != self._id_key:
-            self.set_identity(source_id)
-            self._id_key = key
+        return self.identity_slots(source_id, 1)[0]
+
+    def _default_slots(self, B):
+        if not self._ids:
+            raise RuntimeError("no identity has been set (cs_set_identity): pass source_id or call set_identity first")
+        return [max(self._ids, key=lambda r: r[4])[0]] * B
+
+    @staticmethod
+    def _slot_array(slots):
+        return (C.c_int * len(slots))(*slots)
 
     # ---------------------------------------------------------------- stages
     def extract_feature_3d(self, img):
@@ -117,11 +177,12 @@ class Engine:
         return seg
 
     def swap(self, f, source_id=None):
-        if source_id is not None:
-            self.ensure_identity(source_id)
+        """transfer_model2.forward(x, dlatents): source_id (1,512) or one row per sample (adaptive_modulate.py:157-167)."""
         f = self._in(f, (32, 16, 64, 64))
+        B = f.shape[0]
+        slots = self.identity_slots(source_id, B) if source_id is not None else self._default_slots(B)
         out = self._new(*f.shape)
-        _lib.check(self.lib.cs_swap(self.h, 0, f.shape[0], _ptr(f), _ptr(out), self._stream()), "cs_swap")
+        _lib.check(self.lib.cs_swap_ids(self.h, self._slot_array(slots), B, _ptr(f), _ptr(out), self._stream()), "cs_swap_ids")
         return out
 
     def refine(self, f):
@@ -177,19 +238,16 @@ class Engine:
     def swap_frames(self, img, x_t, x_can, source_id=None, want_f32=True, want_u8=False, debug=False,
                     out_f32=None, out_u8=None):
         """Whole loop body of can_swap_pipeline_e2e.py:242-263 for B frames, on device."""
-        if source_id is not None:
-            self.ensure_identity(source_id)
         img = self._in(img, (3, 256, 256)); x_t = self._in(x_t, (21, 3)); x_can = self._in(x_can, (21, 3))
         self._same_batch(img, x_t, x_can)
         B = img.shape[0]
-        if want_f32 and out_f32 is None:
-            out_f32 = self._new(B, 3, 512, 512)
-        if want_u8 and out_u8 is None:
-            out_u8 = self._new(B, 512, 512, 3, dtype=torch.uint8)
+        slots = self.identity_slots(source_id, B) if source_id is not None else self._default_slots(B)
+        out_f32 = self._out(out_f32, (B, 3, 512, 512), torch.float32) if (want_f32 or out_f32 is not None) else None
+        out_u8 = self._out(out_u8, (B, 512, 512, 3), torch.uint8) if (want_u8 or out_u8 is not None) else None
         rec = self._new(B, 3, 512, 512) if debug else None
         swp = self._new(B, 3, 512, 512) if debug else None
-        _lib.check(self.lib.cs_swap_frames(self.h, 0, B, _ptr(img), _ptr(x_t), _ptr(x_can), _ptr(out_f32), _ptr(out_u8),
-                                           _ptr(rec), _ptr(swp), self._stream()), "cs_swap_frames")
+        _lib.check(self.lib.cs_swap_frames_ids(self.h, self._slot_array(slots), B, _ptr(img), _ptr(x_t), _ptr(x_can), _ptr(out_f32),
+                                               _ptr(out_u8), _ptr(rec), _ptr(swp), self._stream()), "cs_swap_frames_ids")
         res = {"out": out_f32, "out_u8": out_u8}
         if debug:
             res.update(rec_can=rec, swap_can=swp)
@@ -203,10 +261,8 @@ class Engine:
         f = self._in(f, (32, 16, 64, 64)); kp_source = self._in(kp_source, (21, 3))
         if f.shape[0] not in (1, B) or kp_source.shape[0] not in (1, B):
             raise ValueError("f and kp_source must hold 1 or B entries")
-        if want_f32 and out_f32 is None:
-            out_f32 = self._new(B, 3, 512, 512)
-        if want_u8 and out_u8 is None:
-            out_u8 = self._new(B, 512, 512, 3, dtype=torch.uint8)
+        out_f32 = self._out(out_f32, (B, 3, 512, 512), torch.float32) if (want_f32 or out_f32 is not None) else None
+        out_u8 = self._out(out_u8, (B, 512, 512, 3), torch.uint8) if (want_u8 or out_u8 is not None) else None
         _lib.check(self.lib.cs_animate_frames(self.h, B, _ptr(f), f.shape[0], _ptr(kp_source), kp_source.shape[0], _ptr(kp_driving),
                                               _ptr(out_f32), _ptr(out_u8), self._stream()), "cs_animate_frames")
         return {"out": out_f32, "out_u8": out_u8}

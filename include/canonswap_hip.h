@@ -33,6 +33,9 @@ int cs_upload(cs_engine* e, const char* name, const void* host_ptr, size_t nbyte
 int cs_finalize_weights(cs_engine* e);
 /* Per-identity precompute of the 14 modulated+demodulated conv weights of T
  * (AdaptiveSharedWeightConv2d.forward, src/modules/adaptive_modulate.py:148-155).  id: device, 512 fp32. */
+#define CS_MAX_IDENTITY_SLOTS 8
+/* slot in [0, CS_MAX_IDENTITY_SLOTS): each slot keeps its own 14 modulated weight sets (about 132 MB), so several source
+ * identities stay resident (concurrent streams, BASELINE configs[4]) and may be mixed inside one batch (cs_swap_ids). */
 int cs_set_identity(cs_engine* e, int slot, const float* id, void* stream);
 
 /* ---- stage calls; B frames per call, B <= max_batch --------------------------------------------------- */
@@ -46,6 +49,9 @@ int cs_warp(cs_engine* e, int B, const float* f, const float* kp_source, const f
 int cs_warp_out(cs_engine* e, int B, const float* f, const float* occ, float* seg_out, void* stream);
 /* transfer_model2.forward(x, dlatents) == can_swapper.swap (adaptive_modulate.py:522-554), identity from slot */
 int cs_swap(cs_engine* e, int slot, int B, const float* f, float* f_out, void* stream);
+/* the same with one identity slot per sample (slots: B host ints): the reference's per-sample dlatents, i.e. the groups=N
+ * modulated convolution of AdaptiveSharedWeightConv2d.forward (adaptive_modulate.py:157-167) */
+int cs_swap_ids(cs_engine* e, const int* slots, int B, const float* f, float* f_out, void* stream);
 /* G3d.forward (adaptive_modulate.py:721-733) */
 int cs_refine(cs_engine* e, int B, const float* f, float* f_out, void* stream);
 /* WarpingNetwork.forward(feature_3d, kp_driving=, kp_source=) (warping_network.py:83-111):
@@ -67,6 +73,9 @@ int cs_unpack_u8(cs_engine* e, int B, const uint8_t* img, float* out, int H, int
  * (debug decodes of lines 248 / 257, Bx3x512x512) may each be NULL. */
 int cs_swap_frames(cs_engine* e, int slot, int B, const float* img, const float* x_t, const float* x_can,
                    float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream);
+/* cs_swap_frames with one identity slot per frame (slots: B host ints) */
+int cs_swap_frames_ids(cs_engine* e, const int* slots, int B, const float* img, const float* x_t, const float* x_can,
+                       float* out_f32, uint8_t* out_u8, float* rec_can, float* swap_can, void* stream);
 /* The per-frame body of the video-to-image pipeline (can_swap_pipeline_v2i.py:311-312):
  * warp_decode(f, kp_source, kp_driving) -> 3x512x512 for B driving frames.  f: nf x 32x16x64x64 feature volumes and
  * kp_source: ns x 21x3, with nf / ns = 1 (one swapped canonical volume / key-point set shared by all frames) or B;
@@ -101,6 +110,7 @@ typedef struct cs_conv_desc {
     int cfg;                  /* -1 auto conv_igemm, 0..3 conv_igemm tile cfg, -2 auto conv_halo, 10..18 conv_halo tile cfg */
     int tile_w, tile_h;       /* 0 = auto */
     int ck;                   /* conv_halo channel chunk: 0 auto, 32 or 64 */
+    int xcd_map;              /* conv_halo workgroup -> tile mapping: 0 engine default, k > 0 forces mapping k - 1 (common.h) */
 } cs_conv_desc;
 int cs_op_conv(const cs_conv_desc* d, void* stream);
 int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,

@@ -21,7 +21,7 @@ def strides_cl(t):
 
 def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0="none", slope0=0.0, res=None, res_shift=0,
          pixscale=None, ps_stride=1, out0=None, s2=None, t2=None, act1="none", slope1=0.0, out1=None, stats=None,
-         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0):
+         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0, xcd_map=None):
     """x: [N, D, H, W, C] fp16 view (C contiguous). out0/out1/res: 5-D channels-last views. k = (KD, KH, KW)."""
     lib = _lib.load()
     d = _lib.ConvDesc()
@@ -56,6 +56,7 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
     d.mode, d.cfg = mode, cfg
     d.tile_w, d.tile_h = tile
     d.ck = ck
+    d.xcd_map = 0 if xcd_map is None else xcd_map + 1
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.cs_op_conv(C.byref(d), st), "cs_op_conv")
 

@@ -1,0 +1,117 @@
+"""Identity slots of T (BASELINE configs[4]: several source identities resident / mixed in one batch).
+
+Reference semantics: AdaptiveSharedWeightConv2d.forward takes one dlatent row per sample and runs a groups=N modulated
+convolution (adaptive_modulate.py:148-167).  The engine keeps one modulated weight set per identity slot and picks the set per
+sample inside the T launches.  Tolerances as in test_gpu_stages.py (relative L2 on features, PSNR >= 50 dB on frames).
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def swapper(state_dicts):
+    from canonswap_amd.can_swap_e2e import can_swapper
+    return can_swapper(None, state_dicts=state_dicts, max_batch=4)
+
+
+@pytest.fixture(scope="module")
+def feats():
+    r = np.random.Generator(np.random.PCG64(21))
+    return torch.from_numpy((0.08 * r.standard_normal((4, 32, 16, 64, 64))).astype(np.float32))
+
+
+def _ids(*seeds):
+    from canonswap_amd import synth
+    return torch.cat([torch.from_numpy(synth.make_identity(s)) for s in seeds], dim=0)
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def test_two_identities_in_one_batch_vs_oracle(swapper, state_dicts, feats):
+    from oracle import canonswap_ref as O
+    ids = _ids(7, 8, 7, 8)
+    with torch.no_grad():
+        ref = O.transfer(state_dicts["transfer"], feats, ids)            # per-row dlatents
+    got = swapper.swap_module(feats.cuda(), ids.cuda())
+    for b in range(4):
+        assert _rel(got[b], ref[b]) < 3e-3, b
+    # a mixed batch is bit-identical to the same samples run with one identity per call
+    a = swapper.swap_module(feats[0::2].contiguous().cuda(), ids[:1].cuda())
+    c = swapper.swap_module(feats[1::2].contiguous().cuda(), ids[1:2].cuda())
+    assert torch.equal(got[0], a[0]) and torch.equal(got[2], a[1]) and torch.equal(got[1], c[0]) and torch.equal(got[3], c[1])
+    assert not torch.equal(got[0], swapper.swap_module(feats[:1].cuda(), ids[1:2].cuda())[0])
+
+
+def test_mixed_identities_whole_frame(swapper, state_dicts):
+    from canonswap_amd import synth
+    from oracle import canonswap_ref as O
+    inp = synth.make_frame_inputs(2, seed=515, size=256)
+    args = [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")]
+    ids = _ids(3, 29)
+    out = swapper.swap_frames(*(a.cuda() for a in args), ids.cuda())["out"].cpu()
+    for b in range(2):
+        with torch.no_grad():
+            ref = O.swap_frame(state_dicts, *(a[b:b + 1] for a in args), ids[b:b + 1])["out"]
+        assert O.psnr(out[b:b + 1], ref) >= 50.0, b
+
+
+def test_identity_cache_is_keyed_by_value_not_address(swapper, feats):
+    """a new identity tensor allocated at a freed tensor's address must not be mistaken for the old identity.
+    The engine resolves identities by value; its per-frame fast path (same tensor object, same version) holds a strong
+    reference to that tensor, so the block cannot be recycled while it is the cache key."""
+    f = feats[:1].cuda()
+    want_b = swapper.swap_module(f, _ids(8).cuda()).clone()
+    a = _ids(7).cuda()
+    out_a = swapper.swap_module(f, a).clone()
+    addr = a.data_ptr()
+    del a
+    gc.collect()
+    held, b = [], None
+    for _ in range(16):                       # try to get the freed block back from the caching allocator
+        cand = _ids(8).cuda()
+        if cand.data_ptr() == addr:
+            b = cand
+            break
+        held.append(cand)
+    b = b if b is not None else held[-1]
+    out_b = swapper.swap_module(f, b)
+    assert not torch.equal(out_a, out_b)
+    assert torch.equal(out_b, want_b), "address reused: %s" % (b.data_ptr() == addr)
+    # in-place change of the very same tensor object (same address, new version)
+    b.copy_(_ids(7).cuda())
+    assert torch.equal(swapper.swap_module(f, b), out_a)
+    # a distinct tensor with equal contents resolves to the same slot
+    assert torch.equal(swapper.swap_module(f, _ids(7).cuda()), out_a)
+
+
+def test_more_identities_than_slots_evicts_least_recently_used(swapper, feats):
+    from canonswap_amd import _lib
+    f = feats[:1].cuda()
+    outs = [swapper.swap_module(f, _ids(100 + k).cuda()).clone() for k in range(_lib.MAX_IDENTITY_SLOTS + 2)]
+    for k in (0, 1, _lib.MAX_IDENTITY_SLOTS + 1):
+        assert torch.equal(swapper.swap_module(f, _ids(100 + k).cuda()), outs[k])
+    with pytest.raises(ValueError):
+        r = np.random.Generator(np.random.PCG64(1))
+        many = torch.from_numpy(r.standard_normal((_lib.MAX_IDENTITY_SLOTS + 1, 512)).astype(np.float32))
+        swapper.engine.identity_slots(many, _lib.MAX_IDENTITY_SLOTS + 1)
+
+
+def test_output_buffers_are_validated(swapper):
+    from canonswap_amd import synth
+    inp = synth.make_frame_inputs(1, seed=5, size=256)
+    args = [torch.from_numpy(inp[k]).cuda() for k in ("img", "x_t", "x_can")]
+    sid = _ids(7).cuda()
+    with pytest.raises(ValueError):
+        swapper.engine.swap_frames(*args, sid, out_u8=torch.empty(1, 512, 512, 3, dtype=torch.uint8))             # host buffer
+    with pytest.raises(ValueError):
+        swapper.engine.swap_frames(*args, sid, out_f32=torch.empty(1, 3, 512, 512, dtype=torch.float16, device="cuda"))
+    with pytest.raises(ValueError):
+        swapper.engine.swap_frames(*args, sid, out_u8=torch.empty(2, 512, 512, 3, dtype=torch.uint8, device="cuda")[:, :, :, :])

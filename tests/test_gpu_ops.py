@@ -254,3 +254,53 @@ def test_chan_stats(dtype, Cc, P):
     xf = x.double()
     assert torch.allclose(st[..., 0].double(), xf.mean(1), rtol=1e-5, atol=1e-6)
     assert torch.allclose(st[..., 1].double(), 1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5), rtol=1e-4)
+
+
+@pytest.mark.parametrize("xmap", [1, 2])
+@pytest.mark.parametrize("shape", ["2d_multi_cblk", "3d_v32", "2d_odd_tiles"])
+def test_conv_xcd_map_bit_equal(xmap, shape):
+    """The XCD-aware workgroup -> (tile, channel block) mappings (ConvParams::xcd_map) only permute which workgroup computes
+    which tile: outputs, including the per-tile statistics-free epilogue paths, are bit-identical to the identity mapping."""
+    import hip_ops as ops
+    r = _rng(77)
+    if shape == "2d_multi_cblk":
+        N, Cin, Cout, D, H, W, k, cfg, tile = 3, 64, 512, 1, 32, 32, (1, 3, 3), 10, (0, 0)
+    elif shape == "3d_v32":
+        N, Cin, Cout, D, H, W, k, cfg, tile = 2, 32, 32, 16, 16, 16, (3, 3, 3), 12, (4, 4)
+    else:   # 3 x (24 x 8 / 128) tiles: not a multiple of 8
+        N, Cin, Cout, D, H, W, k, cfg, tile = 3, 64, 256, 1, 8, 16, (1, 3, 3), 10, (0, 0)
+    x = _to_cl(_randn(r, N, Cin, D, H, W)).to(DEV)
+    w = _randn(r, Cout, Cin, *k, scale=1.0 / np.sqrt(Cin * np.prod(k)))
+    wp = ops.packed_weight(w, Cout, DEV)
+    b = _randn(r, Cout, scale=0.1).to(DEV)
+    outs = []
+    for m in (0, xmap):
+        out = torch.zeros(N, D, H, W, Cout, dtype=torch.float32, device=DEV)
+        ops.conv(x, wp, Cout, Cout, k, bias=b, act0="relu", out0=out, cfg=cfg, tile=tile, xcd_map=m)
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert float(outs[0].abs().max()) > 0
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("k,tile", [((3, 3, 3), (8, 8)), ((7, 7, 1), (2, 8))])
+@pytest.mark.parametrize("cfg", [18, 19])
+def test_conv_160_wide_tiles(k, tile, cfg):
+    """The hourglass tail (3x3x3, 144 -> 144 of 160 packed) and the kw-split mask conv (7x7x1, 144 -> 160) on the 128- and the
+    256-position 160-channel tiles; ragged channel count (142 real inputs in 144) and a batch the 256-position tile does not divide."""
+    import hip_ops as ops
+    r = _rng(31 + cfg)
+    N, Cin, Cout, D, H, W = 3, 142, 150, 16, 16, 16
+    x = _randn(r, N, Cin, D, H, W)
+    w = _randn(r, Cout, Cin, *k, scale=1.0 / np.sqrt(Cin * np.prod(k)))
+    b = _randn(r, Cout, scale=0.1)
+    ref = F.relu(_ref_conv(x, w, b, tuple(kk // 2 for kk in k)))
+    buf = torch.zeros(N, D, H, W, 144, dtype=torch.float16, device=DEV)
+    buf[..., :Cin] = _to_cl(x).to(DEV)
+    wp = ops.packed_weight(w, 160, DEV)
+    b160 = torch.zeros(160); b160[:Cout] = b
+    out = torch.zeros(N, D, H, W, 160, dtype=torch.float32, device=DEV)
+    ops.conv(buf, wp, 160, 160, k, cin=144, bias=b160.to(DEV), act0="relu", out0=out, cfg=cfg, tile=tile)
+    torch.cuda.synchronize()
+    assert ops.rel_err(_from_cl(out[..., :Cout]), ref) < 2e-3
+    assert float(out[..., Cout:].abs().max()) == 0.0

@@ -126,3 +126,23 @@ def test_upsampled_conv3d_phase_decomposition():
         xp = F.pad(torch.from_numpy(x), (pw, 1 - pw, ph, 1 - ph, 1, 1))
         out[:, :, :, a::2, b::2] = F.conv3d(xp, torch.from_numpy(wab)).numpy()
     assert np.abs(out - ref).max() < 1e-12
+
+
+def test_getid_arithmetic_with_injected_network():
+    """can_swap_e2e.py:102-107: nearest resize to 112x112 -> identity network -> L2 normalisation; the network is injected."""
+    from canonswap_amd.can_swap_e2e import can_swapper
+
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            assert x.shape[-2:] == (112, 112)
+            return x.mean(dim=(2, 3)).repeat(1, 171)[:, :512] + 0.25, None      # (id, aux) like the reference's ArcFace module
+
+    host = type("H", (), {"netArc": Net()})()
+    img = torch.rand(2, 3, 160, 160)
+    got = can_swapper.getid(host, img)
+    want, _ = Net()(F.interpolate(img, size=(112, 112)))
+    want = F.normalize(want, p=2, dim=1)
+    assert got.shape == (2, 512) and torch.allclose(got, want) and torch.allclose(got.norm(dim=1), torch.ones(2))
+    host.netArc = None
+    with pytest.raises(RuntimeError, match="identity network"):
+        can_swapper.getid(host, img)
