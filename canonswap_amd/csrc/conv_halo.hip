@@ -63,6 +63,7 @@ GROUP_FN(1)     // mlp_shared phase convs (1x2x2 family, ahead of the generic 12
         if (p.KW == 2) return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 14>(p, st);
         return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 15>(p, st);
     }
+    if (cfg == CFG_H_256x64 && mode == MODE_STD && ck == 32) return launch_halo_cfg<32, 8, 2, 2, 2, MODE_STD, false, 7>(p, st);
     if (cfg == CFG_H_256x160 && mode == MODE_STD && ck == 32) {
         if (p.KD == 7) return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 8>(p, st);
         return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 7>(p, st);

@@ -16,6 +16,7 @@
 //
 // LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #ifdef CS_TIMELINE
 #define EP_TL(i) TL_STAMP(i)
@@ -74,7 +75,7 @@ template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK
 // unrolled 128x128 tiles (<= 168 VGPRs, no scratch) -- for short-K convs a third workgroup hides the prologue / epilogue
 // of the other two (gamma/beta convs K = 9 x 128: +15 % over the 128x256 tile, tools/ab_conv.sh); the dynamic-shape
 // variants would spill at that budget and stay unconstrained.
-__global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 && !SK && ST != 0) ? 3 : 1))) conv_halo_kernel(const ConvParams p)
+__global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 && !SK && ST != 0) ? (WVP == 2 ? 2 : 3) : 1))) conv_halo_kernel(const ConvParams p)
 {
     using SS = StaticShape<ST>;
     static_assert(ST == 0 || !SK, "static shapes are not combined with split-K");
@@ -479,10 +480,9 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
     if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1);
     hipError_t e;
+    ConvParams kp = p;
 #ifdef CS_TIMELINE
-    ConvParams kp = p; kp.tl = g_cs_tl; kp.tl_cap = g_cs_tl_cap;
-#else
-    const ConvParams& kp = p;
+    kp.tl = g_cs_tl; kp.tl_cap = g_cs_tl_cap;
 #endif
     if (db) {
         auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, true, SK, ST>;

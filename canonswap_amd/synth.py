@@ -25,6 +25,11 @@ def _rng(seed: int, key: str) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64([seed, zlib.crc32(key.encode())]))
 
 
+# weight families (precision-robustness tests): "uniform" = the default bounded init; "heavy_tail" = Student-t(3) weights of the
+# same variance (a few weights per filter are 5-10 sigma, as in trained networks); see also rescale_feature_volume()
+FAMILY = "uniform"
+
+
 class _Builder:
     def __init__(self, seed: int, prefix: str):
         self.seed, self.prefix = seed, prefix
@@ -36,8 +41,14 @@ class _Builder:
     def conv(self, name, cout, cin, *k, bias=True, gain=1.0, wname="weight"):
         fan_in = cin * int(np.prod(k)) if k else cin
         bound = gain * np.sqrt(3.0 / fan_in)  # unit-variance preserving for unit-variance input
-        self.sd[f"{name}.{wname}"] = self._r(f"{name}.{wname}").uniform(
-            -bound, bound, size=(cout, cin, *k)).astype(np.float32)
+        r = self._r(f"{name}.{wname}")
+        if FAMILY == "heavy_tail":
+            # Student-t with 3 degrees of freedom has variance 3: scale to the variance of U(-bound, bound) = bound^2 / 3
+            w = r.standard_t(3, size=(cout, cin, *k)) * (bound / 3.0)
+            w = np.clip(w, -12 * bound / np.sqrt(3.0), 12 * bound / np.sqrt(3.0))
+            self.sd[f"{name}.{wname}"] = w.astype(np.float32)
+        else:
+            self.sd[f"{name}.{wname}"] = r.uniform(-bound, bound, size=(cout, cin, *k)).astype(np.float32)
         if bias:
             self.sd[f"{name}.bias"] = self._r(f"{name}.bias").uniform(-0.1, 0.1, size=(cout,)).astype(np.float32)
 
@@ -225,11 +236,61 @@ def _motion_extractor(seed):
 _BUILDERS["motion_extractor"] = _motion_extractor
 
 
-def make_state_dicts(seed: int = 0, modules=MODULES) -> dict:
+def make_state_dicts(seed: int = 0, modules=MODULES, family: str = "uniform") -> dict:
     """Return ``{module_name: OrderedDict[str, np.ndarray]}`` laid out like the reference's
     ``combined_weights.pth`` (``src/can_swap_e2e.py:87-100``).  The motion extractor is built on
-    request: ``modules=MODULES + ("motion_extractor",)``."""
-    return {m: _BUILDERS[m](seed) for m in modules}
+    request: ``modules=MODULES + ("motion_extractor",)``.  family: "uniform" (default) or "heavy_tail"."""
+    global FAMILY
+    prev, FAMILY = FAMILY, family
+    try:
+        return {m: _BUILDERS[m](seed) for m in modules}
+    finally:
+        FAMILY = prev
+
+
+def rescale_feature_volume(sds: dict, s: float) -> dict:
+    """A weight family whose 32x16x64x64 feature volumes (f_s, f_can, f_swap, f_refined) are s times those of `sds` while the
+    network function stays the same in exact arithmetic: every producer of the volume is scaled by s and every consumer's
+    normalisation statistics / gates absorb it (BatchNorm running_mean * s, running_var * s^2; convs and biases that add to the
+    residual stream * s; T's mask conv / s; GroupNorm affine * s).  What a trained checkpoint may do to the dynamic range of the
+    fp16 tensors - used by the precision-robustness tests with s = 10, 0.1 and 100."""
+    out = {m: OrderedDict((k, np.array(v, copy=True)) for k, v in sd.items()) for m, sd in sds.items()}
+    s = float(s)
+
+    def mul(sd, key, f):
+        sd[key] = (sd[key].astype(np.float64) * f).astype(sd[key].dtype)
+
+    def bn_in(sd, p):        # BatchNorm whose INPUT is scaled by s
+        mul(sd, p + ".running_mean", s); mul(sd, p + ".running_var", s * s)
+
+    def rb3d(sd, p):         # ResBlock3d: norm1 sees the stream, conv2 adds to it
+        bn_in(sd, p + ".norm1"); mul(sd, p + ".conv2.weight", s); mul(sd, p + ".conv2.bias", s)
+
+    F_ = out["appearance_feature_extractor"]
+    mul(F_, "second.weight", s); mul(F_, "second.bias", s)
+    for i in range(6):
+        rb3d(F_, f"resblocks_3d.3dr{i}")
+    W_ = out["warping_module"]
+    bn_in(W_, "dense_motion_network.norm")      # BN after compress (conv bias is inside the BN input: scale it too)
+    mul(W_, "dense_motion_network.compress.weight", 1.0)     # input * s -> output * s (linear)
+    mul(W_, "dense_motion_network.compress.bias", s)
+    mul(W_, "third.conv.bias", s); bn_in(W_, "third.norm")
+    T_ = out["transfer"]
+    for i in range(7):
+        for cv in ("conv1", "conv2"):
+            n = f"BottleNeck_2d.{i}.{cv}"
+            mul(T_, n + ".bias_param", s)                     # out_mod + bias must scale with the stream
+            mul(T_, n + ".mask_conv.0.weight", 1.0 / s)       # the gate keeps its value
+    for i in range(6):
+        rb3d(T_, f"resblocks_3d.3dr{i}")
+    R_ = out["refine"]
+    for blk in ("resblocks1", "resblocks3"):
+        for i in range(3):
+            mul(R_, f"{blk}.{i}.gn2.weight", s); mul(R_, f"{blk}.{i}.gn2.bias", s)    # GroupNorm output joins the stream
+    for i in range(3):
+        n = f"resblocks2.{i}"
+        bn_in(R_, n + ".norm1"); mul(R_, n + ".conv2.weight", s); mul(R_, n + ".conv2.bias", s)
+    return out
 
 
 def to_torch(sds: dict) -> dict:

@@ -304,3 +304,25 @@ def test_conv_160_wide_tiles(k, tile, cfg):
     torch.cuda.synchronize()
     assert ops.rel_err(_from_cl(out[..., :Cout]), ref) < 2e-3
     assert float(out[..., Cout:].abs().max()) == 0.0
+
+
+def test_conv_256x64_tile():
+    """3x3x3, 112 -> 64 (first hourglass encoder block) on the 256-position x 64-channel tile against the 128x64 one."""
+    import hip_ops as ops
+    r = _rng(41)
+    N, Cin, Cout, D, H, W = 2, 110, 64, 16, 16, 16
+    x = _randn(r, N, Cin, D, H, W)
+    w = _randn(r, Cout, Cin, 3, 3, 3, scale=1.0 / np.sqrt(Cin * 27))
+    b = _randn(r, Cout, scale=0.1)
+    ref = F.relu(_ref_conv(x, w, b, (1, 1, 1)))
+    buf = torch.zeros(N, D, H, W, 144, dtype=torch.float16, device=DEV)
+    buf[..., 32:32 + Cin] = _to_cl(x).to(DEV)
+    wp = ops.packed_weight(w, 64, DEV)
+    outs = []
+    for cfg in (11, 20):
+        out = torch.zeros(N, D, H, W, 64, dtype=torch.float16, device=DEV)
+        ops.conv(buf[..., 32:], wp, 64, 64, (3, 3, 3), cin=112, bias=b.to(DEV), act0="relu", out0=out, cfg=cfg, tile=(8, 8))
+        torch.cuda.synchronize()
+        assert ops.rel_err(_from_cl(out), ref) < 3e-3
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])        # same K order per output element: bit-identical across tile shapes

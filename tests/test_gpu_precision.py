@@ -1,0 +1,44 @@
+"""Robustness of the fp16-operand engine outside the default synthetic weight family ("no test pushes activations
+toward the fp16 range limit or shrinks the feature-volume scale, which is what a trained checkpoint could do").
+
+Families: heavier-tailed conv weights (Student-t(3), same variance), feature volumes x10, x0.1 and x100
+(synth.rescale_feature_volume).  Gate as everywhere: PSNR >= 50 dB on the 3x512x512 frame against the fp32 CPU oracle run
+with the SAME weights.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PSNR_GATE = 50.0
+
+
+def _weights(family, np_sds):
+    from canonswap_amd import synth
+    if family == "heavy_tail":
+        return synth.make_state_dicts(0, family="heavy_tail")
+    return synth.rescale_feature_volume(np_sds, {"vol_x10": 10.0, "vol_x0.1": 0.1, "vol_x100": 100.0}[family])
+
+
+@pytest.mark.parametrize("family", ["heavy_tail", "vol_x10", "vol_x0.1", "vol_x100"])
+def test_frame_psnr_other_weight_families(family, state_dicts_np):
+    from canonswap_amd import synth
+    from canonswap_amd.can_swap_e2e import can_swapper
+    from oracle import canonswap_ref as O
+    sds = synth.to_torch(_weights(family, state_dicts_np))
+    inp = synth.make_frame_inputs(1, seed=2024, size=256)
+    args = [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")]
+    idv = torch.from_numpy(synth.make_identity(5))
+    with torch.no_grad():
+        ref = O.swap_frame(sds, *args, idv)
+    sw = can_swapper(None, state_dicts=sds, max_batch=1)
+    try:
+        out = sw.swap_frames(*(a.cuda() for a in args), idv.cuda())["out"].cpu()
+        f_s = sw.extract_feature_3d(args[0].cuda()).cpu()
+    finally:
+        sw.engine.close()
+    rel = float((f_s - ref["f_s"]).norm() / ref["f_s"].norm())
+    p = O.psnr(out, ref["out"])
+    print(f"{family}: PSNR {p:.2f} dB, f_s rel {rel:.2e}, |f_s| max {float(ref['f_s'].abs().max()):.3g}, f_ref max {float(ref['f_ref'].abs().max()):.3g}")
+    assert rel < 5e-3, (family, rel)
+    assert p >= PSNR_GATE, (family, p)

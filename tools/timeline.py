@@ -75,6 +75,8 @@ def cases(B, r):
                                   out0=torch.empty(Bd, 16, 64, 64, 160, dtype=torch.float32, device=DEV), cfg=19, tile=(2, 8)), 245, 8 * 5, 1))
     out.append(("W.enc0", dict(x=xd[..., :112], w=wgt(112, 64, (3, 3, 3)), cout_pad=64, cout=64, k=(3, 3, 3), act0="relu", cin=112,
                                out0=torch.empty(Bd, 16, 64, 64, 64, dtype=torch.float16, device=DEV), cfg=11, tile=(8, 8)), 108, 4 * 2, 2))
+    out.append(("W.enc0_256", dict(x=xd[..., :112], w=wgt(112, 64, (3, 3, 3)), cout_pad=64, cout=64, k=(3, 3, 3), act0="relu", cin=112,
+                                   out0=torch.empty(Bd, 16, 64, 64, 64, dtype=torch.float16, device=DEV), cfg=20, tile=(8, 8)), 108, 8 * 2, 2))
     return out
 
 
