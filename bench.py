@@ -29,7 +29,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "32")))
+    ap.add_argument("--frames", type=int, default=0,
+                    help="fixed-size job (BASELINE configs[3]: --frames 1200): one step = one pass over a video of this many frames, "
+                         "sharded over the ranks in contiguous blocks (strong scaling). Default 0: every rank runs --batch frames "
+                         "per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-crc", default="", help="rank 0 writes the CRC32 of every gathered frame of the last step here (tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: dry run of the multi-rank flow with all ranks sharing GPU 0 and host-side collectives (test only)")
     a = ap.parse_args()
@@ -58,6 +63,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     B, K, Wm = a.batch, a.steps, a.warmup
+    strong = a.frames > 0
+    n_total = a.frames if strong else B * world                 # frames per step over all ranks
+    f0, f1 = parallel.shard_range(n_total, rank, world)         # this rank's contiguous block of every step
+    n_local = f1 - f0
     sds = synth.to_torch(synth.make_state_dicts(0))                     # random-init weights of the real architecture
     sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), state_dicts=sds, max_batch=B)
     eng = sw.engine
@@ -68,18 +77,25 @@ def main():
     sid = sid.to(dev)
     eng.set_identity(sid)
 
-    # synthetic inputs resident in HBM: a pool of 4 distinct batches per rank, cycled over the steps
-    pool = []
-    for j in range(4):
-        inp = synth.make_frame_inputs(B, seed=1000 + 10007 * rank + 131 * j, size=256)
-        pool.append([torch.from_numpy(inp[k]).to(dev) for k in ("img", "x_t", "x_can")])
-    out_u8 = torch.empty(K * B, 512, 512, 3, dtype=torch.uint8, device=dev)
+    # synthetic inputs resident in HBM: a pool of 4 x B distinct frames.  Frame g of a step (global index) reads pool frame
+    # (g + 131 * step) mod 4B, so the result of a frame does not depend on how many ranks share the job.
+    P = 4 * B
+    inp = synth.make_frame_inputs(P, seed=1000, size=256)
+    pool = {k: torch.from_numpy(inp[k]).to(dev) for k in ("img", "x_t", "x_can")}
+    out_u8 = torch.empty(max(n_local, 1), 512, 512, 3, dtype=torch.uint8, device=dev)
 
-    def step(i, slot):
-        eng.swap_frames(*pool[i % 4], want_f32=False, want_u8=True, out_u8=out_u8[slot * B:(slot + 1) * B])
+    def step(i, gather=None):
+        """One step: this rank's block of the job in chunks of B frames; finished chunks go to rank 0 asynchronously."""
+        for t0 in range(0, n_local, B):
+            n = min(B, n_local - t0)
+            idx = (torch.arange(f0 + t0, f0 + t0 + n, device=dev) + 131 * i) % P
+            eng.swap_frames(pool["img"][idx], pool["x_t"][idx], pool["x_can"][idx], want_f32=False, want_u8=True, out_u8=out_u8[t0:t0 + n])
+            if gather is not None:
+                gather.push(out_u8[t0:t0 + n].to(cdev))
+        return gather.finish() if gather is not None else None
 
     for i in range(Wm):
-        step(i, 0)
+        step(i)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -89,9 +105,11 @@ def main():
 
     sync()
     t0 = time.perf_counter()
+    gathered = None
     for i in range(K):
-        step(i, i)
-    gathered = parallel.gather_frames(out_u8.to(cdev), K * B * world, dst=0) if world > 1 else out_u8   # final gather over xGMI
+        g = parallel.ChunkedFrameGather(n_total, B, device=cdev) if world > 1 else None     # chunked gather over xGMI, overlapped
+        r = step(i, g)
+        gathered = r if world > 1 else out_u8[:n_local]
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -99,14 +117,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        assert gathered.shape[0] == K * B * world
+        assert gathered.shape[0] == n_total
+        if a.dump_crc:
+            import zlib
+            fr = gathered.cpu().numpy()
+            with open(a.dump_crc, "w") as f:
+                json.dump([zlib.crc32(fr[k].tobytes()) for k in range(fr.shape[0])], f)
 
     # ---- roofline of the dominant kernel family (conv_igemm): HIP events around every launch, same workload
     prof = None
     if rank == 0:
         eng.profile_begin()
         for i in range(K):
-            step(i, i)
+            step(i)
         prof = eng.profile_end()
     if world > 1:
         dist.barrier()
@@ -114,7 +137,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import canonswap_ref as O          # cpu_baseline leg: the oracle timed on this node's host cores
-        cores = min(os.cpu_count() or 1, 32)           # oversubscribing a 256-thread host slows PyTorch-CPU down
+        cores = min(os.cpu_count() or 1, 32)           # threads used ("cores"); more than 32 slows PyTorch-CPU down on this path
         torch.set_num_threads(cores)
         inp = synth.make_frame_inputs(1, seed=1000, size=256)
         cargs = [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")]
@@ -124,7 +147,7 @@ def main():
         for _ in range(n_cpu):
             O.swap_frame(sds, *cargs, cid)
         cdt = time.perf_counter() - t1
-        cpu = {"value": round(n_cpu / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        cpu = {"value": round(n_cpu / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
                "sample": f"{n_cpu} frames (1 warm-up), batch 1, fp32 PyTorch-CPU restatement of the same path (oracle/)"}
 
     traffic, traffic_src = None, None
@@ -137,34 +160,40 @@ def main():
             traffic_src = "profiles/hbm_traffic.json: " + t["source"]
 
     if rank == 0:
-        frames = K * B * world
+        frames = K * n_total
         fps = frames / dt
         conv_s = prof["conv_ms"] / 1e3
         achieved = prof["conv_flops"] / conv_s / 1e12
         line = {
             "metric": "frames/sec at 512x512 (generator hot path F->W->T->R->W->G)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 512x512 video, frames batched on each GPU (256x256 crops in, "
-                                   "random-init weights of the real architecture)",
-                       "frames_per_step_per_gpu": B, "frames_total": frames, "parallelism": f"frame-shard x{world}",
+            "config": {"workload": (f"BASELINE configs[3]: 512x512 video of {n_total} frames sharded over {world} GPU(s) in contiguous "
+                                    "blocks" if strong else "BASELINE configs[2]: 512x512 video, frames batched on each GPU") +
+                                   " (256x256 crops in, random-init weights of the real architecture)",
+                       "frames_per_step": n_total, "frames_per_launch_per_gpu": B, "frames_total": frames,
+                       "parallelism": f"frame-shard x{world}",
                        "accumulate": "fp32", "debug_decodes": False},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per conv launch",
                          "traffic_source": traffic_src,
                          "kernel": "conv_halo + conv_igemm (every convolution launch)", "launches_per_step": prof["conv_launches"] // K,
                          "avg_launch_us": round(prof["conv_ms"] * 1e3 / prof["conv_launches"], 2),
-                         "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * B) / 1e9, 1),
+                         "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * n_local) / 1e9, 1),
+                         # MFMA work actually issued (padded channel counts, phase-decomposed up-sampling convs): the utilisation of the
+                         # matrix pipe, as opposed to the algorithmic rate above
+                         "executed_tflops": round(prof["exec_flops"] / conv_s / 1e12, 2),
+                         "executed_frac": round(prof["exec_flops"] / conv_s / 1e12 / PEAK_TFLOPS_F16, 4),
                          "other_kernels_ms_per_step": round((prof["other_ms"] + prof["warp_ms"]) / K, 3),
                          "conv_ms_per_step": round(prof["conv_ms"] / K, 3),
                          "end_to_end_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / world / (PEAK_TFLOPS_F16 * 1e12), 4)},
             # the HBM-bound row of the path: trilinear feature warp (F.grid_sample, warping_network.py:46-47), fp32 volumes:
             # algorithmic bytes per frame and call = 8.39 MB in + 0.79 MB grid + 8.39 MB out (+ 4.19 MB fp16 copy on the first call)
             "warp_roofline": {"bound": "hbm", "kernel": "grid_sample_kernel",
-                              "achieved": round((2 * 17.56e6 + 4.19e6) * B * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
+                              "achieved": round((2 * 17.56e6 + 4.19e6) * n_local * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s",
-                              "frac": round((2 * 17.56e6 + 4.19e6) * B * K / (prof["warp_ms"] / 1e3) / 8e12, 4),
+                              "frac": round((2 * 17.56e6 + 4.19e6) * n_local * K / (prof["warp_ms"] / 1e3) / 8e12, 4),
                               "avg_launch_us": round(prof["warp_ms"] * 1e3 / max(prof["warp_launches"], 1), 2), "traffic": None},
             "cpu_baseline": cpu,
         }

@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_halo.hip", "kernels.hip", "motion.hip", "engine.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_halo.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
 HEADERS = [os.path.join(CSRC, f) for f in ("common.h", "conv_epilogue.h", "conv_halo_kernel.h")] + \
           [os.path.join(os.path.dirname(HERE), "include", "canonswap_hip.h")]
 HALO_NGROUPS = 8          # conv_halo.hip is compiled once per -DHALO_GROUP=k (slices of its instantiation table)
@@ -20,7 +20,8 @@ LIB_PATH = os.environ.get("CANONSWAP_LIB") or os.path.join(HERE, "libcanonswap_h
 ABI_SYMBOLS = [
     "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity",
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
-    "cs_pack_u8", "cs_unpack_u8", "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_op_conv", "cs_op_grid_sample3d",
+    "cs_pack_u8", "cs_unpack_u8", "cs_soft_erosion", "cs_prepare_crops", "cs_warp_affine_u8", "cs_warp_affine_f32", "cs_paste_back",
+    "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
     "cs_op_chan_stats", "cs_op_chan_stats_partial_floats",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
@@ -137,10 +138,17 @@ def load():
     lib.cs_pack_u8.argtypes = [vp, ci, vp, vp, ci, ci, vp]
     lib.cs_unpack_u8.argtypes = [vp, ci, vp, vp, ci, ci, vp]
     lib.cs_motion_extract.argtypes = [vp, ci, vp, vp, vp]
+    d6 = C.POINTER(C.c_double)
+    lib.cs_soft_erosion.argtypes = [vp, ci, ci, ci, vp, vp, ci, cf, ci, vp, vp, vp]
+    lib.cs_prepare_crops.argtypes = [vp, ci, vp, ci, ci, vp, vp]
+    lib.cs_warp_affine_u8.argtypes = [vp, vp, ci, ci, d6, vp, ci, ci, vp]
+    lib.cs_warp_affine_f32.argtypes = [vp, vp, ci, ci, d6, vp, ci, ci, vp]
+    lib.cs_paste_back.argtypes = [vp, vp, vp, vp, ci, ci, d6, vp, vp, ci, ci, vp]
     lib.cs_animate_frames.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp]
     lib.cs_swap_frames.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cs_profile_begin.argtypes = [vp]
     lib.cs_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    lib.cs_profile_exec_flops.argtypes = [vp, C.POINTER(C.c_double)]
     lib.cs_op_conv.argtypes = [C.POINTER(ConvDesc), vp]
     lib.cs_op_grid_sample3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.cs_op_chan_stats.argtypes = [vp, ci, ci, C.c_long, ci, cf, vp, vp, vp]

@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from . import tail
 from .engine import Engine
 
 
@@ -149,8 +150,13 @@ class can_swapper(object):
 
     # ---- data preparation (:126-163)
     def prepare_source(self, img: np.ndarray) -> torch.Tensor:
-        if img.shape[0] != 256 or img.shape[1] != 256:
-            raise ValueError("prepare_source expects the 256x256 crop produced by the cropper")
+        hw = img.shape[-3:-1]
+        if tuple(hw) == (512, 512) and img.dtype == np.uint8:
+            # the cropper's 512x512 crop: its cv2.resize(..., (256, 256), INTER_AREA) (cropper.py:209) runs on the device; the
+            # reference's own fallback here (cv2.resize, INTER_LINEAR, :131-132) gives the same 2x2 means at exactly half size
+            return tail.prepare_crops(self.engine, img)
+        if tuple(hw) != (256, 256):
+            raise ValueError("prepare_source expects the 256x256 (or 512x512 uint8) crop produced by the cropper")
         if img.dtype == np.uint8:                 # upload 1 byte per sample and convert on the device (same arithmetic)
             return self.engine.unpack_u8(img[np.newaxis] if img.ndim == 3 else img)
         if img.ndim == 3:
@@ -173,6 +179,25 @@ class can_swapper(object):
             return self.engine.unpack_u8(_imgs[..., 0]).unsqueeze(1)          # T x 1 x 3 x H x W
         y = np.clip(_imgs.astype(np.float32) / 255., 0, 1)
         return torch.from_numpy(y).permute(0, 4, 3, 1, 2).to(self.device)
+
+    # ---- additions: image-space steps around the generator on the device
+    def stream_videos(self, crops_u8, batch: int = None):
+        """Iterator over (I_batch (n,3,256,256) fp32, (start, stop)): uint8 crops uploaded batch by batch, the next upload
+        overlapping the current batch's work, instead of prepare_videos' whole-video residency."""
+        return tail.FrameStreamer(self.engine, crops_u8, batch or self.engine.max_batch)
+
+    def soft_mask(self, kernel_size=21, threshold=0.9, iterations=3):
+        """SoftErosion as the pipeline builds it (can_swap_pipeline_e2e.py:42), on the engine."""
+        return tail.SoftErosion(self.engine, kernel_size, threshold, iterations)
+
+    def paste_back(self, img_crop, M_c2o, img_ori, mask_ori):                           # crop.py:523-529
+        return tail.paste_back(self.engine, img_crop, M_c2o, img_ori, mask_ori)
+
+    def prepare_paste_back(self, mask_crop, crop_M_c2o, dsize):                         # crop.py:515-521 (if_float=True)
+        return tail.prepare_paste_back(self.engine, mask_crop, crop_M_c2o, dsize)
+
+    def paste_back_fused(self, img_crop, mask_crop, M_c2o, img_ori):
+        return tail.paste_back_fused(self.engine, img_crop, mask_crop, M_c2o, img_ori)
 
     # ---- stages
     def extract_feature_3d(self, x: torch.Tensor) -> torch.Tensor:                      # (:165-172)

@@ -91,6 +91,8 @@ struct cs_engine {
     float *m_x = nullptr, *m_sumsq = nullptr, *m_scale = nullptr;
     half_t *m_y = nullptr, *m_h = nullptr;   // split-precision GEMM operands [hi | lo | hi]
     float* m_h32 = nullptr;
+    // soft-erosion scratch (allocated on first use for the largest B*H*W seen)
+    float *se_a = nullptr, *se_b = nullptr, *se_part = nullptr; size_t se_cap = 0;
 
     // ---- workspace
     half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
@@ -111,7 +113,7 @@ struct cs_engine {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;
-    double flops = 0;
+    double flops = 0, flops_exec = 0;
 
     hipEvent_t ev()
     {
@@ -282,6 +284,8 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
 {
     const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
     e->flops += fl;
+    // MFMA work actually issued: packed (padded) channel counts and the taps this launch really runs
+    e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * (c.p.nchunks * 32.0) * c.p.KD * c.p.KH * c.p.KW;
     if (halo_enabled() && c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
@@ -1189,10 +1193,66 @@ extern "C" int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, co
     return 0;
 }
 
+// ---- image-space steps around the generator
+extern "C" int cs_soft_erosion(cs_engine* e, int B, int H, int W, const float* mask, const float* w, int ksize, float thr, int iters,
+                               float* soft_out, uint8_t* hard_out, void* stream)
+{
+    if (!e || !mask || !w || !soft_out || B < 1 || H < 1 || W < 1) { cs_set_error("cs_soft_erosion: bad arguments"); return -1; }
+    DevGuard guard(e->dev);
+    const size_t need = (size_t)B * H * W;
+    if (need > e->se_cap) {      // grow-only scratch; buffers of earlier sizes stay owned by the engine until cs_destroy
+        if (e->alloc(&e->se_a, need) || e->alloc(&e->se_b, need)) return -1;
+        if (!e->se_part && e->alloc(&e->se_part, (size_t)64 * 64)) return -1;
+        e->se_cap = need;
+    }
+    if (B > 64) { cs_set_error("cs_soft_erosion: batch %d exceeds 64", B); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_soft_erosion(mask, e->se_a, e->se_b, w, e->se_part, soft_out, hard_out, B, H, W, ksize, thr, iters, st); },
+                  "soft_erosion");
+}
+
+extern "C" int cs_prepare_crops(cs_engine* e, int B, const uint8_t* crops, int Hc, int Wc, float* out, void* stream)
+{
+    if (!e || !crops || !out || B < 1) { cs_set_error("cs_prepare_crops: bad arguments"); return -1; }
+    if (!((Hc == 256 && Wc == 256) || (Hc == 512 && Wc == 512))) {
+        cs_set_error("cs_prepare_crops: crops must be 256x256 or 512x512 (got %dx%d)", Hc, Wc);
+        return -1;
+    }
+    DevGuard guard(e->dev);
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_prepare_crops(crops, out, B, Hc, Wc, Hc / 256, st); }, "prepare_crops");
+}
+
+extern "C" int cs_warp_affine_u8(cs_engine* e, const uint8_t* src, int Hs, int Ws, const double M[6], uint8_t* dst, int Hd, int Wd, void* stream)
+{
+    if (!e || !src || !dst || !M || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1) { cs_set_error("cs_warp_affine_u8: bad arguments"); return -1; }
+    DevGuard guard(e->dev);
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_paste(src, nullptr, nullptr, Hs, Ws, M, nullptr, dst, Hd, Wd, st); }, "warp_affine_u8");
+}
+
+extern "C" int cs_warp_affine_f32(cs_engine* e, const float* src, int Hs, int Ws, const double M[6], float* dst, int Hd, int Wd, void* stream)
+{
+    if (!e || !src || !dst || !M || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1) { cs_set_error("cs_warp_affine_f32: bad arguments"); return -1; }
+    DevGuard guard(e->dev);
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_warp_f32(src, Hs, Ws, M, dst, Hd, Wd, st); }, "warp_affine_f32");
+}
+
+extern "C" int cs_paste_back(cs_engine* e, const uint8_t* crop, const float* mask_crop, const float* mask_ori, int Hc, int Wc,
+                             const double M_c2o[6], const uint8_t* img_ori, uint8_t* out, int Ho, int Wo, void* stream)
+{
+    if (!e || !crop || !M_c2o || !img_ori || !out || Hc < 1 || Wc < 1 || Ho < 1 || Wo < 1) { cs_set_error("cs_paste_back: bad arguments"); return -1; }
+    if ((mask_crop != nullptr) == (mask_ori != nullptr)) { cs_set_error("cs_paste_back: pass exactly one of mask_crop / mask_ori"); return -1; }
+    DevGuard guard(e->dev);
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_paste(crop, mask_crop, mask_ori, Hc, Wc, M_c2o, img_ori, out, Ho, Wo, st); }, "paste_back");
+}
+
 extern "C" int cs_profile_begin(cs_engine* e)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
-    e->prof = true; e->recs.clear(); e->evnext = 0; e->flops = 0;
+    e->prof = true; e->recs.clear(); e->evnext = 0; e->flops = 0; e->flops_exec = 0;
     return 0;
 }
 
@@ -1213,6 +1273,13 @@ extern "C" int cs_profile_end(cs_engine* e, double ms[3], long counts[3], double
     if (csv) fclose(csv);
     if (flops) *flops = e->flops;
     e->prof = false; e->recs.clear(); e->evnext = 0;
+    return 0;
+}
+
+extern "C" int cs_profile_exec_flops(cs_engine* e, double* flops)
+{
+    if (!e || !flops) { cs_set_error("cs_profile_exec_flops: bad arguments"); return -1; }
+    *flops = e->flops_exec;
     return 0;
 }
 

@@ -1,0 +1,244 @@
+// Image-space steps on either side of the generator, on the device:
+//   * SoftErosion of the face-parsing mask (src/utils/crop.py:21-47),
+//   * paste-back of the generated crop into the original frame: cv2.warpAffine of crop and mask + blend
+//     (src/utils/crop.py:49-63, 515-529, driven from can_swap_pipeline_e2e.py:267-283),
+//   * input staging: cv2.resize(crop, (256,256), INTER_AREA) + /255 + HWC->CHW (src/utils/cropper.py:209, can_swap_e2e.py:126-163).
+// All of them are HBM-bound byte / float work: one thread per output pixel, coalesced along the row.  The OpenCV steps follow
+// OpenCV's published fixed-point algorithm (restated in oracle/cv_ref.py, which the tests compare against bit for bit).
+#include "common.h"
+
+// Bit-exact restatements of CPU arithmetic (numpy / OpenCV evaluate a * b + c with two roundings): no FMA contraction in this file.
+// Plain operators on purpose: the __fmul_rn / __fadd_rn intrinsics are header functions compiled with contraction allowed, and
+// once inlined their multiply and add fuse again.  The fp32 convolution of SoftErosion asks for fmaf explicitly.
+#pragma clang fp contract(off)
+
+#define LAUNCH_CHECK(name)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = hipGetLastError();                                                       \
+        if (_e != hipSuccess) { cs_set_error(name " launch: %s", hipGetErrorString(_e)); return -1; } \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- SoftErosion
+// one pass: out = conv2d(in, w, padding = r) [zero padding], optionally out = min(in, out)  (crop.py:38-41)
+template <int KS>
+__global__ void __launch_bounds__(256) se_conv_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                                      int H, int W, int take_min)
+{
+    constexpr int R = KS / 2, TW = 32, TH = 8, LW = TW + 2 * R, LH = TH + 2 * R;
+    __shared__ float tile[LH][LW + 1];
+    __shared__ float wk[KS * KS];
+    const int n = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const float* src = in + (long)n * H * W;
+    for (int i = threadIdx.x; i < KS * KS; i += 256) wk[i] = w[i];
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i % LW, y = y0 + ly - R, x = x0 + lx - R;
+        tile[ly][lx] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? src[(long)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= W || y >= H) return;
+    float acc = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) acc = fmaf(tile[ty + ky][tx + kx], wk[ky * KS + kx], acc);
+    const float c = tile[ty + R][tx + R];
+    out[(long)n * H * W + (long)y * W + x] = take_min ? fminf(c, acc) : acc;
+}
+
+// max over the pixels below the threshold, per sample (crop.py:45); two deterministic stages (max is order independent)
+__global__ void __launch_bounds__(256) se_max_kernel(const float* __restrict__ x, long P, float thr, float* __restrict__ part)
+{
+    const int n = blockIdx.y;
+    float m = -INFINITY;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long)gridDim.x * 256) {
+        const float v = x[(long)n * P + i];
+        if (!(v >= thr)) m = fmaxf(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[n * gridDim.x + blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+}
+
+__global__ void __launch_bounds__(256) se_final_kernel(float* __restrict__ x, long P, float thr, const float* __restrict__ part, int nparts,
+                                                       unsigned char* __restrict__ hard)
+{
+    const int n = blockIdx.y;
+    float m = -INFINITY;
+    for (int i = 0; i < nparts; ++i) m = fmaxf(m, part[n * nparts + i]);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float v = x[(long)n * P + i];
+    const bool hi = v >= thr;
+    x[(long)n * P + i] = hi ? 1.f : v / m;          // x[mask] = 1; x[~mask] /= x[~mask].max()
+    if (hard) hard[(long)n * P + i] = hi ? 1 : 0;
+}
+
+int launch_soft_erosion(const float* mask, float* tmp_a, float* tmp_b, const float* w, float* part, float* soft, unsigned char* hard,
+                        int B, int H, int W, int ksize, float thr, int iters, hipStream_t st)
+{
+    if (ksize != 21 && ksize != 15) { cs_set_error("soft_erosion: kernel size %d (21 and 15 are built)", ksize); return -1; }
+    if (iters < 1) { cs_set_error("soft_erosion: iterations %d", iters); return -1; }
+    const dim3 grid((W + 31) / 32, (H + 7) / 8, B);
+    const float* src = mask;
+    for (int it = 0; it < iters; ++it) {
+        const bool last = it == iters - 1;
+        float* dst = last ? soft : (it % 2 == 0 ? tmp_a : tmp_b);
+        if (ksize == 21) hipLaunchKernelGGL(se_conv_kernel<21>, grid, dim3(256), 0, st, src, w, dst, H, W, last ? 0 : 1);
+        else hipLaunchKernelGGL(se_conv_kernel<15>, grid, dim3(256), 0, st, src, w, dst, H, W, last ? 0 : 1);
+        LAUNCH_CHECK("se_conv");
+        src = dst;
+    }
+    const long P = (long)H * W;
+    const int nparts = 64;
+    hipLaunchKernelGGL(se_max_kernel, dim3(nparts, B), dim3(256), 0, st, soft, P, thr, part);
+    LAUNCH_CHECK("se_max");
+    hipLaunchKernelGGL(se_final_kernel, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, st, soft, P, thr, part, nparts, hard);
+    LAUNCH_CHECK("se_final");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- input staging
+// cv2.resize(INTER_AREA) by exactly 2 in both directions for 8-bit images: (a + b + c + d + 2) >> 2; then / 255, clip, CHW
+__global__ void __launch_bounds__(256) prepare_crops_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int B, int Hd, int Wd,
+                                                            int factor)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long P = (long)Hd * Wd;
+    if (i >= (long)B * P) return;
+    const int n = (int)(i / P), y = (int)((i % P) / Wd), x = (int)(i % Wd);
+    const int Ws = Wd * factor;
+    const unsigned char* s = in + ((long)n * Hd * factor + (long)y * factor) * Ws * 3 + (long)x * factor * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v;
+        if (factor == 2) v = (s[c] + s[3 + c] + s[(long)Ws * 3 + c] + s[(long)Ws * 3 + 3 + c] + 2) >> 2;
+        else v = s[c];
+        out[((long)n * 3 + c) * P + (long)y * Wd + x] = fminf(fmaxf((float)v / 255.f, 0.f), 1.f);
+    }
+}
+
+int launch_prepare_crops(const unsigned char* in, float* out, int B, int Hc, int Wc, int factor, hipStream_t st)
+{
+    const long n = (long)B * (Hc / factor) * (Wc / factor);
+    hipLaunchKernelGGL(prepare_crops_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, B, Hc / factor, Wc / factor, factor);
+    LAUNCH_CHECK("prepare_crops");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- cv2.warpAffine, INTER_LINEAR
+struct AffineInv { double m[6]; };      // destination -> source map (what warpAffine derives from M)
+
+// OpenCV's fixed-point source coordinate of destination pixel (x, y): AB_BITS = 10, INTER_BITS = 5 (imgwarp.cpp warpAffine)
+__device__ __forceinline__ void affine_coords(const AffineInv& A, int x, int y, int& sx, int& sy, int& fx, int& fy)
+{
+    const double AB = 1024.0;
+    const long adelta = (long)rint(A.m[0] * (double)x * AB);
+    const long bdelta = (long)rint(A.m[3] * (double)x * AB);
+    const long X0 = (long)rint((A.m[1] * (double)y + A.m[2]) * AB) + 16;     // AB_SCALE / INTER_TAB_SIZE / 2
+    const long Y0 = (long)rint((A.m[4] * (double)y + A.m[5]) * AB) + 16;
+    const long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    long ix = X >> 5, iy = Y >> 5;
+    ix = ix < -32768 ? -32768 : (ix > 32767 ? 32767 : ix);
+    iy = iy < -32768 ? -32768 : (iy > 32767 ? 32767 : iy);
+    sx = (int)ix; sy = (int)iy; fx = (int)(X & 31); fy = (int)(Y & 31);
+}
+
+// crop (u8, 3 channels) warped into the destination frame; with a mask (warped from the crop frame, or given in the
+// destination frame) and the original image: out = clip(mask * warped + (1 - mask) * ori, 0, 255) truncated (crop.py:523-529)
+__global__ void __launch_bounds__(256) paste_kernel(const unsigned char* __restrict__ crop, const float* __restrict__ mask_crop,
+                                                    const float* __restrict__ mask_ori, int Hc, int Wc, AffineInv A,
+                                                    const unsigned char* __restrict__ ori, unsigned char* __restrict__ out, int Ho, int Wo)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Ho * Wo) return;
+    const int y = (int)(i / Wo), x = (int)(i % Wo);
+    int sx, sy, fx, fy;
+    affine_coords(A, x, y, sx, sy, fx, fy);
+    const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;   // sum 1 << 15
+    const bool y0 = (unsigned)sy < (unsigned)Hc, y1 = (unsigned)(sy + 1) < (unsigned)Hc;
+    const bool x0 = (unsigned)sx < (unsigned)Wc, x1 = (unsigned)(sx + 1) < (unsigned)Wc;
+    int res[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int t00 = (y0 && x0) ? crop[((long)sy * Wc + sx) * 3 + c] : 0;
+        const int t01 = (y0 && x1) ? crop[((long)sy * Wc + sx + 1) * 3 + c] : 0;
+        const int t10 = (y1 && x0) ? crop[((long)(sy + 1) * Wc + sx) * 3 + c] : 0;
+        const int t11 = (y1 && x1) ? crop[((long)(sy + 1) * Wc + sx + 1) * 3 + c] : 0;
+        res[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;
+    }
+    if (!ori) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[i * 3 + c] = (unsigned char)res[c];
+        return;
+    }
+    float m;
+    if (mask_ori) m = mask_ori[i];
+    else {      // float image: table weights (1 - a)(1 - b) ... in float, left-to-right sum without contraction (remapBilinear, float)
+        const float ax = (float)fx * 0.03125f, ay = (float)fy * 0.03125f;
+        const float f00 = (1.f - ay) * (1.f - ax), f01 = (1.f - ay) * ax;
+        const float f10 = ay * (1.f - ax), f11 = ay * ax;
+        const float t00 = (y0 && x0) ? mask_crop[(long)sy * Wc + sx] : 0.f, t01 = (y0 && x1) ? mask_crop[(long)sy * Wc + sx + 1] : 0.f;
+        const float t10 = (y1 && x0) ? mask_crop[(long)(sy + 1) * Wc + sx] : 0.f, t11 = (y1 && x1) ? mask_crop[(long)(sy + 1) * Wc + sx + 1] : 0.f;
+        m = ((t00 * f00 + t01 * f01) + t10 * f10) + t11 * f11;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = m * (float)res[c] + (1.f - m) * (float)ori[i * 3 + c];
+        out[i * 3 + c] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);       // np.clip(...).astype(np.uint8): truncation
+    }
+}
+
+// float image (one channel) warped into the destination frame (prepare_paste_back, crop.py:515-521)
+__global__ void __launch_bounds__(256) warp_f32_kernel(const float* __restrict__ src, int Hs, int Ws, AffineInv A, float* __restrict__ dst,
+                                                       int Hd, int Wd)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)Hd * Wd) return;
+    const int y = (int)(i / Wd), x = (int)(i % Wd);
+    int sx, sy, fx, fy;
+    affine_coords(A, x, y, sx, sy, fx, fy);
+    const bool y0 = (unsigned)sy < (unsigned)Hs, y1 = (unsigned)(sy + 1) < (unsigned)Hs;
+    const bool x0 = (unsigned)sx < (unsigned)Ws, x1 = (unsigned)(sx + 1) < (unsigned)Ws;
+    const float ax = (float)fx * 0.03125f, ay = (float)fy * 0.03125f;
+    const float f00 = (1.f - ay) * (1.f - ax), f01 = (1.f - ay) * ax;
+    const float f10 = ay * (1.f - ax), f11 = ay * ax;
+    const float t00 = (y0 && x0) ? src[(long)sy * Ws + sx] : 0.f, t01 = (y0 && x1) ? src[(long)sy * Ws + sx + 1] : 0.f;
+    const float t10 = (y1 && x0) ? src[(long)(sy + 1) * Ws + sx] : 0.f, t11 = (y1 && x1) ? src[(long)(sy + 1) * Ws + sx + 1] : 0.f;
+    dst[i] = ((t00 * f00 + t01 * f01) + t10 * f10) + t11 * f11;
+}
+
+static AffineInv invert_affine(const double M[6])      // imgwarp.cpp warpAffine, !WARP_INVERSE_MAP
+{
+    AffineInv A;
+    for (int i = 0; i < 6; ++i) A.m[i] = M[i];
+    double D = A.m[0] * A.m[4] - A.m[1] * A.m[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = A.m[4] * D, A22 = A.m[0] * D;
+    A.m[0] = A11; A.m[1] *= -D; A.m[3] *= -D; A.m[4] = A22;
+    const double b1 = -A.m[0] * A.m[2] - A.m[1] * A.m[5];
+    const double b2 = -A.m[3] * A.m[2] - A.m[4] * A.m[5];
+    A.m[2] = b1; A.m[5] = b2;
+    return A;
+}
+
+int launch_paste(const unsigned char* crop, const float* mask_crop, const float* mask_ori, int Hc, int Wc, const double M[6],
+                 const unsigned char* ori, unsigned char* out, int Ho, int Wo, hipStream_t st)
+{
+    const long n = (long)Ho * Wo;
+    hipLaunchKernelGGL(paste_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, crop, mask_crop, mask_ori, Hc, Wc, invert_affine(M),
+                       ori, out, Ho, Wo);
+    LAUNCH_CHECK("paste");
+    return 0;
+}
+
+int launch_warp_f32(const float* src, int Hs, int Ws, const double M[6], float* dst, int Hd, int Wd, hipStream_t st)
+{
+    const long n = (long)Hd * Wd;
+    hipLaunchKernelGGL(warp_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, Hs, Ws, invert_affine(M), dst, Hd, Wd);
+    LAUNCH_CHECK("warp_f32");
+    return 0;
+}

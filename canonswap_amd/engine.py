@@ -274,5 +274,7 @@ class Engine:
     def profile_end(self):
         ms, cnt, fl = (C.c_double * 3)(), (C.c_long * 3)(), C.c_double()
         _lib.check(self.lib.cs_profile_end(self.h, ms, cnt, C.byref(fl)), "cs_profile_end")
-        return {"conv_ms": ms[0], "other_ms": ms[1], "warp_ms": ms[2], "conv_launches": cnt[0], "other_launches": cnt[1],
+        ex = C.c_double()
+        _lib.check(self.lib.cs_profile_exec_flops(self.h, C.byref(ex)), "cs_profile_exec_flops")
+        return {"exec_flops": ex.value,"conv_ms": ms[0], "other_ms": ms[1], "warp_ms": ms[2], "conv_launches": cnt[0], "other_launches": cnt[1],
                 "warp_launches": cnt[2], "conv_flops": fl.value}

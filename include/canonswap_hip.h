@@ -83,12 +83,35 @@ int cs_swap_frames_ids(cs_engine* e, const int* slots, int B, const float* img, 
 int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, const float* kp_source, int ns, const float* kp_driving,
                       float* out_f32, uint8_t* out_u8, void* stream);
 
+/* ---- image-space steps on either side of the generator; all buffers on the device ---- */
+/* SoftErosion.forward (src/utils/crop.py:21-47; the pipeline builds it with kernel_size 21, threshold 0.9, iterations 3 / 2,
+ * can_swap_pipeline_e2e.py:42, _v2i.py:43): mask BxHxW fp32 (0/1) -> soft_out BxHxW fp32, hard_out BxHxW u8 (may be NULL).
+ * w: the ksize x ksize fp32 kernel (crop.py:29-35), built by the caller exactly as the reference builds it. */
+int cs_soft_erosion(cs_engine* e, int B, int H, int W, const float* mask, const float* w, int ksize, float thr, int iters,
+                    float* soft_out, uint8_t* hard_out, void* stream);
+/* Input staging (src/utils/cropper.py:209 + can_swap_e2e.py:126-163): uint8 crops BxHcxWcx3, 512x512 (cv2.resize to 256x256 with
+ * INTER_AREA = 2x2 means, (a+b+c+d+2)>>2) or 256x256 -> Bx3x256x256 fp32 = u8 / 255 */
+int cs_prepare_crops(cs_engine* e, int B, const uint8_t* crops, int Hc, int Wc, float* out, void* stream);
+/* cv2.warpAffine(src, M, dsize=(Wd, Hd), flags=INTER_LINEAR), BORDER_CONSTANT 0 (src/utils/crop.py:49-63 _transform_img):
+ * M: host, 2x3 row major, source -> destination.  8-bit 3-channel and float 1-channel images. */
+int cs_warp_affine_u8(cs_engine* e, const uint8_t* src, int Hs, int Ws, const double M[6], uint8_t* dst, int Hd, int Wd, void* stream);
+int cs_warp_affine_f32(cs_engine* e, const float* src, int Hs, int Ws, const double M[6], float* dst, int Hd, int Wd, void* stream);
+/* paste_back (src/utils/crop.py:523-529) fused with the mask warp of prepare_paste_back (:515-521): crop HcxWcx3 u8, the soft mask
+ * either in the crop frame (mask_crop HcxWc, warped here) or already in the frame of the original image (mask_ori HoxWo) - exactly
+ * one of the two -, M_c2o 2x3 (crop -> original), img_ori / out HoxWox3 u8:
+ * out = clip(mask * warp(crop) + (1 - mask) * img_ori, 0, 255) truncated to 8 bits */
+int cs_paste_back(cs_engine* e, const uint8_t* crop, const float* mask_crop, const float* mask_ori, int Hc, int Wc,
+                  const double M_c2o[6], const uint8_t* img_ori, uint8_t* out, int Ho, int Wo, void* stream);
+
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream */
 int cs_profile_begin(cs_engine* e);
 /* ms[0] = convolution kernels (conv_halo / conv_igemm), ms[1] = all other kernels except ms[2] = the feature warp
  * (grid_sample_kernel); counts likewise; flops = algorithmic conv FLOPs (2*MAC over the reference's logical channel
  * counts) enqueued since cs_profile_begin. CANONSWAP_PROFILE_CSV=<path> additionally dumps one line per launch. */
 int cs_profile_end(cs_engine* e, double ms[3], long counts[3], double* flops);
+/* MFMA FLOPs actually issued by the convolution launches since cs_profile_begin (padded channel counts, the taps the
+ * phase-decomposed up-sampling convs really run): matrix-pipe utilisation, next to the algorithmic figure above */
+int cs_profile_exec_flops(cs_engine* e, double* flops);
 
 /* ---- operator level (unit parity tests) ---------------------------------------------------------------- */
 typedef struct cs_conv_desc {

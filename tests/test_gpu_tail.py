@@ -1,0 +1,87 @@
+"""N2 / N3 on the device (csrc/imgops.hip) against oracle/cv_ref.py: integer / byte work bit-exact; SoftErosion (fp32 conv with
+another summation order than torch) to 2e-6 with at most a handful of threshold flips."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def swapper(state_dicts):
+    from canonswap_amd.can_swap_e2e import can_swapper
+    return can_swapper(None, state_dicts=state_dicts, max_batch=4)
+
+
+def test_soft_erosion_vs_reference_vectors(swapper, golden):
+    g = golden("soft_erosion.npz")
+    for name, (ks, thr, it) in {"e2e": (21, 0.9, 3), "v2i": (21, 0.9, 2)}.items():
+        se = swapper.soft_mask(ks, thr, it)
+        # built on this host with the reference's formula: the fp32 sum that normalises it may differ in the last bit between CPUs
+        assert np.allclose(se.weight.cpu().numpy(), g[name + "_weight"], rtol=1e-6, atol=0)
+        x = torch.from_numpy(np.stack([g[f"{name}_0_in"], g[f"{name}_1_in"]]).astype(np.int32))[:, None]
+        soft, hard = se(x)
+        soft, hard = soft.cpu().numpy()[:, 0], hard.cpu().numpy()[:, 0]
+        for k in (0, 1):
+            flips = hard[k] != g[f"{name}_{k}_hard"]
+            d = np.abs(soft[k] - g[f"{name}_{k}_soft"])[~flips]
+            print(name, k, "hard-mask flips", int(flips.sum()), "max |soft diff| elsewhere", float(d.max()))
+            assert flips.sum() <= 4, (name, k, int(flips.sum()))          # pixels whose conv value sits within rounding of 0.9
+            assert d.max() < 2e-6, (name, k, float(d.max()))
+
+
+def test_prepare_crops_bit_exact(swapper):
+    from oracle import cv_ref as R
+    from oracle import canonswap_ref as O
+    r = np.random.Generator(np.random.PCG64(7))
+    crops = r.integers(0, 256, size=(3, 512, 512, 3), dtype=np.uint8)
+    got = swapper.prepare_source(crops).cpu().numpy()
+    want = np.concatenate([O.prepare_source(R.resize_area_2x_u8(c)).numpy() for c in crops])
+    assert got.shape == (3, 3, 256, 256) and np.array_equal(got, want)
+    small = r.integers(0, 256, size=(2, 256, 256, 3), dtype=np.uint8)
+    from canonswap_amd import tail
+    assert np.array_equal(tail.prepare_crops(swapper.engine, small).cpu().numpy(),
+                          np.concatenate([O.prepare_source(c).numpy() for c in small]))
+
+
+@pytest.mark.parametrize("case", ["upscale_rot", "downscale", "partly_outside"])
+def test_paste_back_bit_exact(swapper, case):
+    from oracle import cv_ref as R
+    r = np.random.Generator(np.random.PCG64(11))
+    crop = r.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)
+    Ho, Wo = (720, 1280) if case != "downscale" else (300, 400)
+    ori = r.integers(0, 256, size=(Ho, Wo, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:512, 0:512].astype(np.float32)
+    mask = np.clip(1.2 - np.hypot(xx - 256, yy - 256) / 200, 0, 1).astype(np.float32)
+    th = {"upscale_rot": 0.3, "downscale": -0.1, "partly_outside": 0.05}[case]
+    sc = {"upscale_rot": 1.13, "downscale": 0.37, "partly_outside": 0.9}[case]
+    tx, ty = {"upscale_rot": (333.25, 41.6), "downscale": (60.1, 20.9), "partly_outside": (-200.5, 500.3)}[case]
+    M = np.array([[sc * np.cos(th), -sc * np.sin(th), tx], [sc * np.sin(th), sc * np.cos(th), ty], [0, 0, 1]], np.float64)
+    mask_ori = R.prepare_paste_back(np.stack([mask] * 3, -1), M, (Wo, Ho))
+    want = R.paste_back(crop, M, ori, mask_ori)
+    got_mask = swapper.prepare_paste_back(mask, M, (Wo, Ho)).cpu().numpy()
+    assert np.array_equal(got_mask, mask_ori[..., 0])
+    from canonswap_amd import tail
+
+    def same(a, b, what):
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        assert d.max() == 0, (what, int((d > 0).sum()), int(d.max()), np.argwhere(d > 0)[:3].tolist())
+
+    same(tail.warp_affine_u8(swapper.engine, crop, M, (Wo, Ho)).cpu().numpy(), R.warp_affine_u8(crop, M[:2], (Wo, Ho)), "warp_u8")
+    same(swapper.paste_back(crop, M, ori, torch.from_numpy(mask_ori)).cpu().numpy(), want, "paste_back")
+    same(swapper.paste_back_fused(crop, mask, M, ori).cpu().numpy(), want, "fused")
+
+
+def test_frame_streamer_equals_whole_video_upload(swapper):
+    from oracle import cv_ref as R
+    from oracle import canonswap_ref as O
+    r = np.random.Generator(np.random.PCG64(13))
+    frames = [r.integers(0, 256, size=(512, 512, 3), dtype=np.uint8) for _ in range(10)]
+    seen = []
+    for I, (a, b) in swapper.stream_videos(frames, batch=4):
+        assert I.shape == (b - a, 3, 256, 256)
+        seen.append((a, b, I.cpu().numpy()))
+    assert [(a, b) for a, b, _ in seen] == [(0, 4), (4, 8), (8, 10)]
+    got = np.concatenate([x for _, _, x in seen])
+    want = np.concatenate([O.prepare_source(R.resize_area_2x_u8(f)).numpy() for f in frames])
+    assert np.array_equal(got, want)
