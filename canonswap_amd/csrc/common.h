@@ -120,7 +120,8 @@ long chan_stats_partial_floats(int N, long P, int C);
 int launch_chan_stats_finish(const float* partials, int nblk, int N, int C, double cnt_inv, float eps, float* stats, hipStream_t st);
 int launch_norm_act(const float* y, const float* stats, const float* gamma, const float* beta,
                     const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
-                    int act2, float slope2, int N, long per_n, hipStream_t st);
+                    int act2, float slope2, int N, long per_n, hipStream_t st, int split = 0);
+int launch_split16(const float* x, half_t* out, long n, hipStream_t st);
 int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,
                          int N, int C, int D, int H, int W, hipStream_t st);
 int launch_hwdc_to_ncdhw(const float* in, float* out, int N, int C, int D, int H, int W, hipStream_t st);

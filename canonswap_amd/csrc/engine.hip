@@ -74,7 +74,7 @@ struct cs_engine {
     const float* mask_b = nullptr;
     TLayer t_l[14];
     Affine t_pre0;
-    struct S3 { ConvL c1, c2; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];
+    struct S3 { ConvL c1, c2, c1sp, c2sp; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];   // *sp: split-precision weights (Cin 96)
     struct RB2 { ConvL c1, c2; Affine pre; } r_rb2[3];
     ConvL g_fc, g_sh64, g_sh128, g_sh256, g_img;
     struct ShPhase { ConvL conv; int a, b0, ph, pw; };     // mlp_shared convs of the up blocks per output phase group on the source grid
@@ -97,6 +97,7 @@ struct cs_engine {
     // ---- workspace
     half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
     float* vs[3]; half_t* va[2];
+    half_t* vsp[2];                        // split-precision conv inputs of R's GroupNorm blocks: [hi | lo | hi] per voxel
     half_t *dm_comp, *dm_l[6], *dm_pre, *dm_pred;
     float *dm_logits, *dm_deform, *dm_occ;
     float *kpbuf;
@@ -533,26 +534,42 @@ int run_T(cs_engine* e, int B, const int* slots, int* cur, hipStream_t st)
 
 // ------------------------------------------------------------------------------------------------ R
 // G3d.forward (adaptive_modulate.py:721-733). x: fp32 vs[*cur] + fp16 va[0]; result fp32 in vs[*cur].
+// Split precision (default on; CANONSWAP_R_SPLIT=0 is the A/B knob): the two convs of a stage-3 block feed GroupNorms, which divide
+// by the std of the conv output - the fp16 rounding of operands there costs 1.5e-3 relative error on the refined volume (every
+// other stage: 1-4e-4) and sets the PSNR of the whole frame (50-57 dB depending on the frame).  With activations [hi | lo | hi]
+// and weights [W_hi | W_hi | W_lo] (three 32-channel chunks) the same fp16 MFMA kernel computes them to about 2^-21.
+bool r_split()
+{
+    static const bool on = [] { const char* s = getenv("CANONSWAP_R_SPLIT"); return s ? atoi(s) != 0 : true; }();
+    return on;
+}
+
+TDesc hwdc3_split(void* p) { return td(p, VOL * 3, 96, (long)FW * FD * 96, (long)FD * 96); }
+
 int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
 {
+    const bool sp = r_split();
+    if (sp) TRY(e->run(1, st, [&] { return launch_split16(e->vs[*cur], e->vsp[0], (long)B * VOL, st); }, "split16"));
     for (int i = 0; i < 3; ++i) {   // ResBlock3D_stage3_leak (util.py:528-544)
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
-        ConvCall c1 = mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
+        ConvCall c1 = sp ? mk(blk[i].c1sp, e->vsp[0], hwdc3_split(nullptr), B, FD, FH, FW) : mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
         c1.hcfg = cfg_v32();
         float* s1;
         TRY(go_stats(e, c1, 32, VOX, &s1, st, 4, 4));
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
-                                                       e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st); }, "norm_act"));
-        ConvCall c2 = mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
+                                                       sp ? e->vsp[1] : e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st, sp); }, "norm_act"));
+        ConvCall c2 = sp ? mk(blk[i].c2sp, e->vsp[1], hwdc3_split(nullptr), B, FD, FH, FW) : mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
         c2.hcfg = cfg_v32();
         float* s2;
         TRY(go_stats(e, c2, 32, VOX, &s2, st, 4, 4));
         const bool pre = (i == 2 && last_pre);
+        const bool sp_out = sp && i < 2;            // the next stage-3 block reads split precision; everything else plain fp16
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s2, blk[i].g2, blk[i].b2, e->vs[*cur], 0.01f,
-                                                       e->vs[nxt], e->va[0], pre ? last_pre->s : nullptr, pre ? last_pre->t : nullptr,
-                                                       512, pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st); }, "norm_act"));
+                                                       e->vs[nxt], sp_out ? e->vsp[0] : e->va[0], pre ? last_pre->s : nullptr,
+                                                       pre ? last_pre->t : nullptr, 512, pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st, sp_out); },
+                    "norm_act"));
         *cur = nxt;
     }
     return 0;
@@ -783,6 +800,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     A(f_t0, B * 65536 * 64); A(f_t1, B * 65536 * 128); A(f_p0, B * 16384 * 128); A(f_t2, B * 16384 * 256); A(f_p1, B * 4096 * 256);
     for (int i = 0; i < 3; ++i) A(vs[i], B * VOL);
     for (int i = 0; i < 2; ++i) A(va[i], B * VOL);
+    for (int i = 0; i < 2; ++i) A(vsp[i], B * VOL * 3);
     A(dm_comp, B * VOX * 4);
     static const long lsz[6] = {65536L * 144, 16L * 1024 * 128, 16L * 256 * 256, 16L * 64 * 512, 16L * 16 * 1024, 16L * 4 * 1024};
     for (int i = 0; i < 6; ++i) A(dm_l[i], B * lsz[i]);
@@ -935,6 +953,8 @@ extern "C" int cs_finalize_weights(cs_engine* e)
             std::string b = n;
             TRY(get_conv(e, b + ".c1", 32, 32, 32, 3, 3, 3, 32, 32.0 * 32 * 27, &s[i].c1));
             TRY(get_conv(e, b + ".c2", 32, 32, 32, 3, 3, 3, 32, 32.0 * 32 * 27, &s[i].c2));
+            TRY(get_conv(e, b + ".c1.sp", 96, 32, 32, 3, 3, 3, 0, 32.0 * 32 * 27, &s[i].c1sp)); s[i].c1sp.b = s[i].c1.b;
+            TRY(get_conv(e, b + ".c2.sp", 96, 32, 32, 3, 3, 3, 0, 32.0 * 32 * 27, &s[i].c2sp)); s[i].c2sp.b = s[i].c2.b;
             TRY(get_f32(e, b + ".gn1.w", 32, &s[i].g1)); TRY(get_f32(e, b + ".gn1.b", 32, &s[i].b1));
             TRY(get_f32(e, b + ".gn2.w", 32, &s[i].g2)); TRY(get_f32(e, b + ".gn2.b", 32, &s[i].b2));
         }

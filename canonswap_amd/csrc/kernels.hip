@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
                                                        const float* __restrict__ res, float slope, float* __restrict__ out32,
                                                        half_t* __restrict__ out16, const float* __restrict__ s2,
                                                        const float* __restrict__ t2, int period2, int act2, float slope2, long per_n,
-                                                       long total4)
+                                                       long total4, int split)
 {
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
     if (i4 >= total4) return;
@@ -484,16 +484,46 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
         o16[r] = (half_t)act_f(a, act2, slope2);
     }
     if (out32) *(float4*)(out32 + i) = make_float4(v[0], v[1], v[2], v[3]);
-    if (out16) *(h4_t*)(out16 + i) = o16;
+    if (out16 && !split) *(h4_t*)(out16 + i) = o16;
+    if (out16 && split) {      // split precision for the next conv: voxel-wise [hi(32) | lo(32) | hi(32)], hi + lo == value to 2^-22
+        h4_t lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lo[r] = (half_t)(v[r] - (float)o16[r]);     // split mode carries no second affine: o16 = fp16(v)
+        half_t* o = out16 + (i >> 5) * 96 + c;
+        *(h4_t*)o = o16; *(h4_t*)(o + 32) = lo; *(h4_t*)(o + 64) = o16;
+    }
+}
+
+// fp32 volume -> split-precision fp16 [hi | lo | hi] per voxel of 32 channels
+__global__ void __launch_bounds__(256) split16_kernel(const float* __restrict__ x, half_t* __restrict__ out, long total4)
+{
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const long i = i4 * 4;
+    const float4 q = *(const float4*)(x + i);
+    const float v[4] = {q.x, q.y, q.z, q.w};
+    h4_t hi, lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { hi[r] = (half_t)v[r]; lo[r] = (half_t)(v[r] - (float)hi[r]); }
+    half_t* o = out + (i >> 5) * 96 + (i & 31);
+    *(h4_t*)o = hi; *(h4_t*)(o + 32) = lo; *(h4_t*)(o + 64) = hi;
+}
+
+int launch_split16(const float* x, half_t* out, long n, hipStream_t st)
+{
+    hipLaunchKernelGGL(split16_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, st, x, out, n / 4);
+    LAUNCH_CHECK("split16");
+    return 0;
 }
 
 int launch_norm_act(const float* y, const float* stats, const float* gamma, const float* beta,
                     const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
-                    int act2, float slope2, int N, long per_n, hipStream_t st)
+                    int act2, float slope2, int N, long per_n, hipStream_t st, int split)
 {
     const long total4 = (long)N * per_n / 4;
+    if (split && s2) { cs_set_error("norm_act: the split-precision output carries no second affine"); return -1; }
     hipLaunchKernelGGL(norm_act_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, y, stats, gamma, beta, res, slope,
-                       out32, out16, s2, t2, period2, act2, slope2, per_n, total4);
+                       out32, out16, s2, t2, period2, act2, slope2, per_n, total4, split);
     LAUNCH_CHECK("norm_act");
     return 0;
 }
