@@ -34,6 +34,11 @@ def main():
                          "sharded over the ranks in contiguous blocks (strong scaling). Default 0: every rank runs --batch frames "
                          "per step (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8-weights", action="store_true",
+                    help="BASELINE configs[4] numerics: conv weights quantised to e4m3 with per-out-channel scales (expanded to f16 for "
+                         "the MFMA, whose operands must share a format class); activations f16")
+    ap.add_argument("--identities", type=int, default=1,
+                    help="configs[4]: this many source identities resident at once, frames of a launch cycling through them")
     ap.add_argument("--dump-crc", default="", help="rank 0 writes the CRC32 of every gathered frame of the last step here (tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: dry run of the multi-rank flow with all ranks sharing GPU 0 and host-side collectives (test only)")
@@ -68,14 +73,18 @@ def main():
     f0, f1 = parallel.shard_range(n_total, rank, world)         # this rank's contiguous block of every step
     n_local = f1 - f0
     sds = synth.to_torch(synth.make_state_dicts(0))                     # random-init weights of the real architecture
-    sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), state_dicts=sds, max_batch=B)
+    sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), state_dicts=sds, max_batch=B,
+                     fp8_weights=a.fp8_weights)
     eng = sw.engine
 
-    # one-time broadcast of the source identity (2 KB); every rank derives T's modulated weights locally
-    sid = torch.from_numpy(synth.make_identity(7)).to(cdev) if rank == 0 else torch.zeros(1, 512, device=cdev)
+    # one-time broadcast of the source identities (2 KB each); every rank derives T's modulated weights locally
+    nid = max(1, min(a.identities, 8))
+    sid = torch.from_numpy(synth.make_identity(7, n=nid)).to(cdev) if rank == 0 else torch.zeros(nid, 512, device=cdev)
     parallel.broadcast_identity(sid, src=0)
     sid = sid.to(dev)
-    eng.set_identity(sid)
+    for k in range(nid):
+        eng.set_identity(sid[k:k + 1], slot=k)
+    frame_ids = sid[torch.arange(B, device=dev) % nid] if nid > 1 else None      # per-frame identity rows of one launch
 
     # synthetic inputs resident in HBM: a pool of 4 x B distinct frames.  Frame g of a step (global index) reads pool frame
     # (g + 131 * step) mod 4B, so the result of a frame does not depend on how many ranks share the job.
@@ -89,7 +98,8 @@ def main():
         for t0 in range(0, n_local, B):
             n = min(B, n_local - t0)
             idx = (torch.arange(f0 + t0, f0 + t0 + n, device=dev) + 131 * i) % P
-            eng.swap_frames(pool["img"][idx], pool["x_t"][idx], pool["x_can"][idx], want_f32=False, want_u8=True, out_u8=out_u8[t0:t0 + n])
+            eng.swap_frames(pool["img"][idx], pool["x_t"][idx], pool["x_can"][idx], None if frame_ids is None else frame_ids[:n],
+                            want_f32=False, want_u8=True, out_u8=out_u8[t0:t0 + n])
             if gather is not None:
                 gather.push(out_u8[t0:t0 + n].to(cdev))
         return gather.finish() if gather is not None else None
@@ -168,12 +178,13 @@ def main():
             "metric": "frames/sec at 512x512 (generator hot path F->W->T->R->W->G)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "f16 activations x e4m3 weights (per-out-channel scale, expanded to f16 for the MFMA)" if a.fp8_weights else "f16",
+            "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[3]: 512x512 video of {n_total} frames sharded over {world} GPU(s) in contiguous "
                                     "blocks" if strong else "BASELINE configs[2]: 512x512 video, frames batched on each GPU") +
                                    " (256x256 crops in, random-init weights of the real architecture)",
                        "frames_per_step": n_total, "frames_per_launch_per_gpu": B, "frames_total": frames,
-                       "parallelism": f"frame-shard x{world}",
+                       "parallelism": f"frame-shard x{world}", "identities_resident": nid,
                        "accumulate": "fp32", "debug_decodes": False},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per conv launch",

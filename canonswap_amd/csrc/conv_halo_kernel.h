@@ -473,10 +473,9 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     // double-buffered halos: up to 64 KB per workgroup (two or three workgroups stay resident); the 256x160 tiles run one workgroup
     // per CU and take what they need
     constexpr bool big = (BM == 256 && WCH == 5);
-    // A/B knob: double-buffer the three 52 KB chunks of the split-precision volume convs (one workgroup per CU instead of three)
-    static const bool v32db = [] { const char* s = getenv("CANONSWAP_V32_DB"); return s && atoi(s) != 0; }();
-    const bool wide = big || (v32db && ST == 3 && nck == 3);
-    const bool db = nck > 1 && 2 * HV * VS <= (wide ? 128 : 64) * 1024 && HV * SLP <= 256 * (wide ? 13 : 8);
+    // (double-buffering the three 52 KB chunks of the split-precision volume convs - one workgroup per CU instead of three single-
+    // buffered ones - measured 3 % slower on the whole step: profiles/r02_notes.md)
+    const bool db = nck > 1 && 2 * HV * VS <= (big ? 128 : 64) * 1024 && HV * SLP <= 256 * (big ? 13 : 8);
     size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
