@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--fp8-weights", action="store_true",
                     help="BASELINE configs[4] numerics: conv weights quantised to e4m3 with per-out-channel scales (expanded to f16 for "
                          "the MFMA, whose operands must share a format class); activations f16")
+    ap.add_argument("--latency-mode", action="store_true",
+                    help="BASELINE configs[1] (--batch 1): cross-workgroup split-K for the launches that cannot fill the chip")
     ap.add_argument("--identities", type=int, default=1,
                     help="configs[4]: this many source identities resident at once, frames of a launch cycling through them")
     ap.add_argument("--dump-crc", default="", help="rank 0 writes the CRC32 of every gathered frame of the last step here (tests)")
@@ -74,7 +76,7 @@ def main():
     n_local = f1 - f0
     sds = synth.to_torch(synth.make_state_dicts(0))                     # random-init weights of the real architecture
     sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), state_dicts=sds, max_batch=B,
-                     fp8_weights=a.fp8_weights)
+                     fp8_weights=a.fp8_weights, latency_mode=a.latency_mode)
     eng = sw.engine
 
     # one-time broadcast of the source identities (2 KB each); every rank derives T's modulated weights locally
@@ -184,7 +186,7 @@ def main():
                                     "blocks" if strong else "BASELINE configs[2]: 512x512 video, frames batched on each GPU") +
                                    " (256x256 crops in, random-init weights of the real architecture)",
                        "frames_per_step": n_total, "frames_per_launch_per_gpu": B, "frames_total": frames,
-                       "parallelism": f"frame-shard x{world}", "identities_resident": nid,
+                       "parallelism": f"frame-shard x{world}", "identities_resident": nid, "latency_mode": bool(a.latency_mode),
                        "accumulate": "fp32", "debug_decodes": False},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per conv launch",

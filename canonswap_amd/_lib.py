@@ -18,7 +18,7 @@ HALO_NGROUPS = 8          # conv_halo.hip is compiled once per -DHALO_GROUP=k (s
 OBJ_DIR = os.path.join(HERE, "build")
 LIB_PATH = os.environ.get("CANONSWAP_LIB") or os.path.join(HERE, "libcanonswap_hip.so")      # CANONSWAP_LIB: A/B builds (tools/)
 ABI_SYMBOLS = [
-    "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity",
+    "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity", "cs_set_latency_mode",
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_unpack_u8", "cs_soft_erosion", "cs_prepare_crops", "cs_warp_affine_u8", "cs_warp_affine_f32", "cs_paste_back",
     "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
@@ -126,6 +126,7 @@ def load():
     lib.cs_upload.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.cs_finalize_weights.argtypes = [vp]
     lib.cs_set_identity.argtypes = [vp, ci, vp, vp]
+    lib.cs_set_latency_mode.argtypes = [vp, ci]
     lib.cs_extract_feature_3d.argtypes = [vp, ci, vp, vp, vp]
     lib.cs_warp.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     lib.cs_warp_out.argtypes = [vp, ci, vp, vp, vp, vp]

@@ -53,7 +53,8 @@ class _Callable:
 class can_swapper(object):
     """MI355X engine behind the reference's ``can_swapper`` interface."""
 
-    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8, id_net=None, fp8_weights: bool = False):
+    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8, id_net=None, fp8_weights: bool = False,
+                 latency_mode: bool = False):
         self.inference_cfg = inference_cfg
         self.device_id = getattr(inference_cfg, "device_id", 0)
         self.compile = False                      # torch.compile switch of the reference (:47,:74-77) has no meaning here
@@ -61,7 +62,7 @@ class can_swapper(object):
             raise RuntimeError("flag_force_cpu=True: this engine runs on an MI355X only (no CPU path)")
         self.device = "cuda:" + str(self.device_id)
         self.fp8_weights = fp8_weights            # BASELINE configs[4]: conv weights quantised to e4m3 (per-out-channel scale)
-        self.engine = Engine(self.device_id, max_batch=max_batch)
+        self.engine = Engine(self.device_id, max_batch=max_batch, latency_mode=latency_mode)
         self.appearance_feature_extractor = _Callable(self.engine.extract_feature_3d)
         self.warping_module = _WarpingModule(self.engine)
         self.spade_generator = _Callable(lambda feature: self.engine.spade_decode(feature))

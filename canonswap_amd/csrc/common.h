@@ -78,6 +78,11 @@ struct ConvParams {
     // Instance/GroupNorm: stat_out[((n*nblk + blk)*Cout + c)*2 + {0,1}], nblk = tiles per sample * waves along positions.
     // Finished by launch_chan_stats_finish (fixed order: deterministic). Requires tiles that lie within one sample.
     float* stat_out;
+    // cross-workgroup split-K for launches with too few tiles to fill 256 CUs (single-frame latency): blockIdx.z = split; every
+    // split writes fp32 partial sums [split][N*D*H*W][Cout_pad] instead of running the epilogue; launch_splitk_finish adds them in
+    // split order (deterministic) and applies bias / activation / output conversion.  nullptr: off.
+    float* sk_out;
+    int sk_splits;
     // workgroup -> (position tile, channel block) mapping (conv_halo): hardware places workgroup b on XCD b % 8 (each XCD has its
     // own L2).  0: blockIdx.x = tile, blockIdx.y = channel block.  1: the same grid, but every XCD walks a contiguous range of
     // tiles (halo overlaps of neighbouring tiles hit in that XCD's L2).  2: flat grid, contiguous range per XCD with the channel
@@ -122,6 +127,7 @@ int launch_norm_act(const float* y, const float* stats, const float* gamma, cons
                     const float* res, float slope, float* out32, half_t* out16, const float* s2, const float* t2, int period2,
                     int act2, float slope2, int N, long per_n, hipStream_t st, int split = 0);
 int launch_split16(const float* x, half_t* out, long n, hipStream_t st);
+int launch_splitk_finish(const ConvParams& p, hipStream_t st);
 int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,
                          int N, int C, int D, int H, int W, hipStream_t st);
 int launch_hwdc_to_ncdhw(const float* in, float* out, int N, int C, int D, int H, int W, hipStream_t st);

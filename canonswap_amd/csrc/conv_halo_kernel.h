@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     const long wstep = (long)p.Cout_pad * 32;
     const int nck = (p.Cin + CK - 1) / CK;
     const int j0 = SK ? wave : 0;
+    // cross-workgroup split-K (ConvParams::sk_out): blockIdx.z owns the channel chunks [cc_lo, cc_hi) and leaves raw partial sums
+    int cc_lo = 0, cc_hi = nck;
+    if (p.sk_out) { cc_lo = (int)(((long)nck * blockIdx.z) / gridDim.z); cc_hi = (int)(((long)nck * (blockIdx.z + 1)) / gridDim.z); }
 
     f4_t acc[WCH][WPX];
 #pragma unroll
@@ -236,25 +239,25 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const u4_t*)(src + ci * 512);
         };
         TL_STAMP(1);
-        stage_halo(0, 0);
+        stage_halo(0, cc_lo * CK);
         __syncthreads();
         TL_STAMP(2);
-        if (DB && nck > 1) stage_halo(1, CK);
-        for (int cc = 0; cc < nck; ++cc) {
+        if (DB && cc_lo + 1 < cc_hi) stage_halo(1, (cc_lo + 1) * CK);
+        for (int cc = cc_lo; cc < cc_hi; ++cc) {
             // prime the ring with this chunk's first steps before waiting on the halo: both latencies overlap
 #pragma unroll
             for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
-            if (cc > 0) {
+            if (cc > cc_lo) {
                 if (DB) {
-                    __syncthreads();                       // chunk cc has landed in buffer cc&1; everyone left the other one
-                    if (cc + 1 < nck) stage_halo((cc + 1) & 1, (cc + 1) * CK);
+                    __syncthreads();                       // chunk cc has landed in buffer (cc-cc_lo)&1; everyone left the other one
+                    if (cc + 1 < cc_hi) stage_halo((cc + 1 - cc_lo) & 1, (cc + 1) * CK);
                 } else {
                     __syncthreads();
                     stage_halo(0, cc * CK);
                     __syncthreads();
                 }
             }
-            const unsigned char* hb = smem + (size_t)(DB ? (cc & 1) : 0) * HV * VS;
+            const unsigned char* hb = smem + (size_t)(DB ? ((cc - cc_lo) & 1) : 0) * HV * VS;
             // Software-pipelined operand fetch: the position fragments are split in two halves; while the MFMAs of one half
             // run, the ds_reads of the other half (of this step or of the next one) are in flight, so no LDS round trip is
             // exposed in steady state and no extra registers are needed.
@@ -304,12 +307,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         };
         struct It { int cc, nh, tap, half; };
         auto it_init = [&](It& it) {
-            it.cc = 0; it.nh = chunk_nhalf(0); it.tap = 0; it.half = j0;
+            it.cc = cc_lo; it.nh = chunk_nhalf(cc_lo); it.tap = 0; it.half = j0;
             while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
         };
         auto it_chunk_done = [&](const It& it) -> bool { return it.tap >= ntaps; };
         auto it_next_chunk = [&](It& it) {
-            ++it.cc; it.nh = it.cc < nck ? chunk_nhalf(it.cc) : 1; it.tap = 0; it.half = j0;
+            ++it.cc; it.nh = it.cc < cc_hi ? chunk_nhalf(it.cc) : 1; it.tap = 0; it.half = j0;
             while (it.half >= it.nh) { it.half -= it.nh; ++it.tap; }
         };
         auto it_advance = [&](It& it) {
@@ -320,8 +323,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         it_init(P);
         long last_off = 0;
         auto wload = [&](u4_t (&dst)[WCH]) {
-            while (P.cc < nck && it_chunk_done(P)) it_next_chunk(P);
-            if (P.cc < nck) { last_off = (long)((P.cc * KH32 + P.half) * ntaps + P.tap) * wstep; it_advance(P); }
+            while (P.cc < cc_hi && it_chunk_done(P)) it_next_chunk(P);
+            if (P.cc < cc_hi) { last_off = (long)((P.cc * KH32 + P.half) * ntaps + P.tap) * wstep; it_advance(P); }
             // past the end the last valid fragment is re-read (never consumed): every step issues exactly WCH loads, so the
             // counted wait below is exact in steady state and conservative otherwise
             const half_t* src = wlane + last_off;
@@ -337,10 +340,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         for (int i = 0; i < PFD; ++i) wload(wr[i]);
 
         TL_STAMP(1);
-        stage_halo(0, 0);
+        stage_halo(0, cc_lo * CK);
         __syncthreads();
         TL_STAMP(2);
-        if (DB && nck > 1) stage_halo(1, CK);
+        if (DB && cc_lo + 1 < cc_hi) stage_halo(1, (cc_lo + 1) * CK);
         int cur = 0;
         It C;                                // consumer
         it_init(C);
@@ -352,10 +355,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     #pragma unroll
             for (int i = 0; i < PFD; ++i) {
                 while (!done && it_chunk_done(C)) {            // this wave finished its share of chunk C.cc
-                    if (C.cc + 1 >= nck) { done = true; break; }
+                    if (C.cc + 1 >= cc_hi) { done = true; break; }
                     if (DB) {
                         __syncthreads();                       // chunk cc+1 has landed in buffer cur^1; everyone left buffer cur
-                        if (C.cc + 2 < nck) stage_halo(cur, (C.cc + 2) * CK);
+                        if (C.cc + 2 < cc_hi) stage_halo(cur, (C.cc + 2) * CK);
                         cur ^= 1;
                     } else {
                         __syncthreads();                       // everyone is done reading the single buffer
@@ -398,10 +401,27 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr bool EP_HEAVY = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
     TL_STAMP(3);
     if constexpr (!SK) {
+        if (p.sk_out) {      // split-K: this workgroup's partial sums, fp32, [split][position][packed channel]; finished by splitk_finish_kernel
+            const long mtot = (long)p.N * p.D * p.H * p.W;
+#pragma unroll
+            for (int pi = 0; pi < WPX; ++pi) {
+                int m = wpx * WPX * 16 + pi * 16 + l15;
+                const int w = (tw << lgTW) + (m & mW); m >>= lgTW;
+                const int h = (th << lgTH) + (m & mH); m >>= lgTH;
+                const int d = (td << lgTD) + (m & mD); m >>= lgTD;
+                const int n = tn * TN + m;
+                if (n >= p.N) continue;
+                const long pos = (((long)n * p.D + d) * p.H + h) * p.W + w;
+#pragma unroll
+                for (int ci = 0; ci < WCH; ++ci)
+                    *(f4_t*)(p.sk_out + ((long)blockIdx.z * mtot + pos) * p.Cout_pad + n0 + wch * WCH * 16 + ci * 16 + l4 * 4) = acc[ci][pi];
+            }
+        } else {
         constexpr int EP_WPX = WPX;
         const int ep_wpx = wpx;
         auto& ep_acc = acc;
         CONV_EPILOGUE()
+        }
     } else {
         // reduce the four waves' partial accumulators through LDS; wave w finishes position blocks 2w, 2w+1
         __syncthreads();                                   // halo no longer needed: reuse it
@@ -480,6 +500,10 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
+    if (p.sk_out) {
+        if (SK || p.sk_splits < 1 || p.sk_splits > nck || p.xcd_map == 2) { cs_set_error("conv_halo: bad split-K launch (%d splits, %d chunks)", p.sk_splits, nck); return -1; }
+        grid.z = (unsigned)p.sk_splits;
+    }
     if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1);
     hipError_t e;
     ConvParams kp = p;

@@ -54,6 +54,7 @@ struct TLayer { ConvL fused; ConvL mask; const float* raw; const float* fc; cons
 struct cs_engine {
     int dev = 0, maxB = 1;
     bool finalized = false;
+    bool latency_mode = false;             // single-frame latency: cross-workgroup split-K for launches that cannot fill the chip
     bool slot_set[MAX_SLOTS] = {};
     int* slot_dev = nullptr;               // per-sample identity slot of the current batch (device)
     int* slot_pin = nullptr;               // pinned staging ring for slot_dev uploads
@@ -97,6 +98,7 @@ struct cs_engine {
     // ---- workspace
     half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
     float* vs[3]; half_t* va[2];
+    float* sk_buf = nullptr; size_t sk_cap = 0;      // split-K partial sums (floats)
     half_t* vsp[2];                        // split-precision conv inputs of R's GroupNorm blocks: [hi | lo | hi] per voxel
     half_t *dm_comp, *dm_l[6], *dm_pre, *dm_pred;
     float *dm_logits, *dm_deform, *dm_occ;
@@ -272,7 +274,9 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     // 128 positions x 256 channels (64 channels per wave) only exists as the fully unrolled 3x3 / 16x8-tile kernel
     // 2 resident 128x256 workgroups win only for the T blend convs (N = 1024, 4 channel blocks per tile: +4.7 %); everywhere
     // else 3 resident 128x128 workgroups are 4-14 % faster (G 3x3 convs, fc, F down-blocks) - measured per layer with tools/cmp_layers.py
-    if (mode == MODE_TBLEND && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0) return CFG_H_128x256;
+    // (below 3 frames a 128x256 launch is 128 workgroups or fewer: 128x128 tiles put one on every CU; same K order, same bits)
+    if (mode == MODE_TBLEND && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0 &&
+        (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     if (Cout_pad % 128 == 0) return CFG_H_128x128;
     if (Cout_pad % 64 == 0) return CFG_H_128x64;
     if (Cout_pad % 32 == 0) return CFG_H_128x32;
@@ -301,6 +305,31 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         }
         const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0) ? 64 : 32;
         c.p.xcd_map = xcd_map_default();
+        {   // cross-workgroup split-K when the launch cannot fill the chip (single-frame latency: the deep hourglass levels run 8-64
+            // workgroups that each stream megabytes of weights): plain bias + activation + one output only
+            // Split sums are added in another order than one workgroup's sequential accumulation, so results differ in the last
+            // bits from the batched path: the engine only does this in latency mode (cs_set_latency_mode), never silently by batch size -
+            // frames of a batch stay bit-identical to the same frames run alone.
+            const bool sk_on = e->latency_mode;
+            const int bn = hcfg == CFG_H_128x256 ? 256 : hcfg == CFG_H_128x128 ? 128 : hcfg == CFG_H_128x64 || hcfg == CFG_H_256x64 ? 64 :
+                           hcfg == CFG_H_128x160 || hcfg == CFG_H_256x160 ? 160 : hcfg == CFG_H_128x16 || hcfg == CFG_H_256x16 ? 16 : 32;
+            const long wgs = (long)c.p.nTW * c.p.nTH * c.p.nTD * c.p.nTN * (c.p.Cout_pad / bn);
+            const int nck = (c.p.Cin + ck - 1) / ck;
+            const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
+            const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
+                               c.p.act0 <= ACT_LRELU && c.p.cg == 0 && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0;
+            if (sk_on && plain && wgs <= 96 && nck >= 4 && e->sk_buf) {
+                int splits = (int)(256 / wgs);
+                if (splits > nck) splits = nck;
+                if (splits > 16) splits = 16;
+                while (splits > 1 && (size_t)splits * mtot * c.p.Cout_pad > e->sk_cap) --splits;
+                if (splits >= 2) {
+                    c.p.sk_out = e->sk_buf; c.p.sk_splits = splits; c.p.xcd_map = 0;
+                    TRY(e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl));
+                    return e->run(1, st, [&] { return launch_splitk_finish(c.p, st); }, "splitk_finish");
+                }
+            }
+        }
         return e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl);
     }
     if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
@@ -810,6 +839,8 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     A(w_t3, B * 4096 * 256); A(seg16, B * 4096 * 256);
     A(tmask, B * 4096 * 4); A(style, 14 * 512);
     A(slot_dev, B);
+    e->sk_cap = (size_t)16 << 20;                       // 64 MB of fp32 partials
+    A(sk_buf, e->sk_cap);
     CS_CHECK_HIP(hipHostMalloc((void**)&e->slot_pin, sizeof(int) * 16 * B));
     e->stats_slots = 48; e->stats_slot_floats = B * 512 * 2;
     A(stats_pool, e->stats_slots * e->stats_slot_floats);
@@ -1293,6 +1324,13 @@ extern "C" int cs_profile_end(cs_engine* e, double ms[3], long counts[3], double
     if (csv) fclose(csv);
     if (flops) *flops = e->flops;
     e->prof = false; e->recs.clear(); e->evnext = 0;
+    return 0;
+}
+
+extern "C" int cs_set_latency_mode(cs_engine* e, int on)
+{
+    if (!e) { cs_set_error("null engine"); return -1; }
+    e->latency_mode = on != 0;
     return 0;
 }
 

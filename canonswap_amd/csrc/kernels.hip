@@ -768,3 +768,45 @@ int launch_lrelu16(const half_t* in, half_t* out, long n, float slope, hipStream
     LAUNCH_CHECK("lrelu16");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// finish of a cross-workgroup split-K convolution (ConvParams::sk_out): sum of the splits in split order, bias, activation,
+// store to out0 (fp16 or fp32, arbitrary position strides)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const ConvParams p, long mtot)
+{
+    const int cq = p.Cout / 4;                                  // 4 channels per thread
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mtot * cq) return;
+    const long pos = i / cq;
+    const int c = (int)(i % cq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.sk_splits; ++k) {
+        const float4 q = *(const float4*)(p.sk_out + ((long)k * mtot + pos) * p.Cout_pad + c);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+    }
+    long r = pos;
+    const int w = (int)(r % p.W); r /= p.W;
+    const int h = (int)(r % p.H); r /= p.H;
+    const int d = (int)(r % p.D); r /= p.D;
+    const long o = r * p.out0.sN + (long)d * p.out0.sD + (long)h * p.out0.sH + (long)w * p.out0.sW + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = act_f(v[k] + (p.bias ? p.bias[c + k] : 0.f), p.act0, p.slope0);
+    if (p.out0_f32) *(float4*)((float*)p.out0.p + o) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+        h4_t x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = (half_t)v[k];
+        *(h4_t*)((half_t*)p.out0.p + o) = x;
+    }
+}
+
+int launch_splitk_finish(const ConvParams& p, hipStream_t st)
+{
+    if (p.res.p || p.pixscale || p.out1.p || p.stat_out || p.s2) { cs_set_error("split-K finish: only bias + activation + one output"); return -1; }
+    const long mtot = (long)p.N * p.D * p.H * p.W;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(cdiv(mtot * (p.Cout / 4), 256)), dim3(256), 0, st, p, mtot);
+    LAUNCH_CHECK("splitk_finish");
+    return 0;
+}

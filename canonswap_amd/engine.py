@@ -20,7 +20,7 @@ def _ptr(t):
 class Engine:
     """One engine per device; not thread-safe (same contract as the C ABI)."""
 
-    def __init__(self, device_id: int = 0, max_batch: int = 8):
+    def __init__(self, device_id: int = 0, max_batch: int = 8, latency_mode: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("canonswap_amd.Engine needs a ROCm device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -30,6 +30,9 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.lib.cs_create(device_id, max_batch, C.byref(h)), "cs_create")
         self.h = h
+        self.latency_mode = bool(latency_mode)
+        if latency_mode:         # BASELINE configs[1]: split-K for launches that cannot fill the chip (see cs_set_latency_mode)
+            _lib.check(self.lib.cs_set_latency_mode(h, 1), "cs_set_latency_mode")
         self._ids = []            # resident identities: [slot, device copy (512,), last tensor seen, its _version, use tick]
         self._tick = 0
 

@@ -38,6 +38,11 @@ int cs_finalize_weights(cs_engine* e);
  * identities stay resident (concurrent streams, BASELINE configs[4]) and may be mixed inside one batch (cs_swap_ids). */
 int cs_set_identity(cs_engine* e, int slot, const float* id, void* stream);
 
+/* Single-frame latency mode (BASELINE configs[1]): launches that cannot fill the 256 CUs (the deep hourglass levels at B = 1) split
+ * their reduction dimension over several workgroups and sum the parts in a fixed order.  Deterministic, within the same tolerance
+ * as the batched path, but not bit-identical to it (another summation order) - hence a mode, never chosen silently from the batch. */
+int cs_set_latency_mode(cs_engine* e, int on);
+
 /* ---- stage calls; B frames per call, B <= max_batch --------------------------------------------------- */
 /* can_swapper.extract_feature_3d (can_swap_e2e.py:165-172): img Bx3x256x256 -> f Bx32x16x64x64 */
 int cs_extract_feature_3d(cs_engine* e, int B, const float* img, float* f_out, void* stream);
