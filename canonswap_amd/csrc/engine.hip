@@ -317,7 +317,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const int nck = (c.p.Cin + ck - 1) / ck;
             const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
             const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
-                               c.p.act0 <= ACT_LRELU && c.p.cg == 0 && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0;
+                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0;
             if (sk_on && plain && wgs <= 96 && nck >= 4 && e->sk_buf) {
                 int splits = (int)(256 / wgs);
                 if (splits > nck) splits = nck;
@@ -485,7 +485,9 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
     oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 16); oc.p.out0_f32 = 1;
     if (halo_enabled()) {
-        oc.hcfg = CFG_H_SK128x32;     // 7 real output channels, 560 K-steps: the four waves split the K-steps (0.27 -> 0.20 ms at B = 16)
+        // 7 real output channels, 560 K-steps: the four waves split the K-steps (0.27 -> 0.20 ms at B = 16); in latency mode the
+        // K-steps are split over workgroups instead (32 tiles cannot fill the chip)
+        oc.hcfg = e->latency_mode ? CFG_H_128x32 : CFG_H_SK128x32;
         TRY(go(e, oc, st));
     } else {
         cs_set_error("the occlusion conv needs conv_halo (grouped input channels)");

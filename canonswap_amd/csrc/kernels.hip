@@ -398,21 +398,25 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict_
 __global__ void __launch_bounds__(256) chan_stats_finish_kernel(const float* __restrict__ partials, int nblk, int C, int NC, double cnt_inv,
                                                                 float eps, float* __restrict__ stats)
 {
-    // workgroup = 16 channels x 16 lanes over the partials; fixed-order fp64 tree -> deterministic
-    __shared__ double red[2][16][17];
-    const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + cl;      // (n, c) flat index, NC multiple of 16
+    // workgroup = 4 channels x 64 lanes over the partials (the kernel is latency-bound: the deeper the fan-out over the partial
+    // blocks, the fewer dependent loads per thread); fixed-order fp64 reduction -> deterministic
+    __shared__ double red[2][64][4];
+    const int cl = threadIdx.x & 3, bl = threadIdx.x >> 2;
+    const int i = blockIdx.x * 4 + cl;       // (n, c) flat index, NC multiple of 4
     const int n = i / C, c = i % C;
     double s = 0, ss = 0;
-    for (int b = bl; b < nblk; b += 16) {
+    for (int b = bl; b < nblk; b += 64) {
         const float2 q = *(const float2*)(partials + (((long)n * nblk + b) * C + c) * 2);
         s += q.x; ss += q.y;
     }
     red[0][bl][cl] = s; red[1][bl][cl] = ss;
     __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {       // pairwise tree over the 64 block lanes, same shape every time
+        if (bl < o) { red[0][bl][cl] += red[0][bl + o][cl]; red[1][bl][cl] += red[1][bl + o][cl]; }
+        __syncthreads();
+    }
     if (bl == 0) {
-        s = 0; ss = 0;
-        for (int j = 0; j < 16; ++j) { s += red[0][j][cl]; ss += red[1][j][cl]; }
+        s = red[0][0][cl]; ss = red[1][0][cl];
         const double mean = s * cnt_inv;
         double var = ss * cnt_inv - mean * mean;
         if (var < 0) var = 0;
@@ -428,7 +432,7 @@ long chan_stats_partial_floats(int N, long P, int C) { return (long)N * cdiv(P, 
 int launch_chan_stats_finish(const float* partials, int nblk, int N, int C, double cnt_inv, float eps, float* stats, hipStream_t st)
 {
     if (C % 16) { cs_set_error("chan_stats_finish: unsupported C=%d", C); return -1; }
-    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 16)), dim3(256), 0, st, partials, nblk, C, N * C, cnt_inv, eps, stats);
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, partials, nblk, C, N * C, cnt_inv, eps, stats);
     LAUNCH_CHECK("chan_stats_finish");
     return 0;
 }
@@ -442,7 +446,7 @@ int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps
     if (is_f32) hipLaunchKernelGGL(chan_stats_kernel<true>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     else hipLaunchKernelGGL(chan_stats_kernel<false>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     LAUNCH_CHECK("chan_stats");
-    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 16)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
                        1.0 / (double)P, eps, stats);
     LAUNCH_CHECK("chan_stats_finish");
     return 0;
@@ -452,6 +456,7 @@ __device__ __forceinline__ float act_f(float v, int act, float slope)
 {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
+    if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));       // same form as the conv epilogue (conv_epilogue.h apply_act)
     return v;
 }
 
