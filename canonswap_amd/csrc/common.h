@@ -83,6 +83,9 @@ struct ConvParams {
     // split order (deterministic) and applies bias / activation / output conversion.  nullptr: off.
     float* sk_out;
     int sk_splits;
+    // split-precision convs (activations [hi | lo], weights [W_hi | W_lo | W_hi] in three 32-channel chunks): weight chunks 0 and 1 both
+    // multiply the activation chunk 0 (hi), chunk 2 multiplies activation chunk 1 (lo) - the hi halo is staged once.  0: off.
+    int hilo;
     // workgroup -> (position tile, channel block) mapping (conv_halo): hardware places workgroup b on XCD b % 8 (each XCD has its
     // own L2).  0: blockIdx.x = tile, blockIdx.y = channel block.  1: the same grid, but every XCD walks a contiguous range of
     // tiles (halo overlaps of neighbouring tiles hit in that XCD's L2).  2: flat grid, contiguous range per XCD with the channel

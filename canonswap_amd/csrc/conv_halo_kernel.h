@@ -207,16 +207,17 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         const int dl = m & mD; m >>= lgTD;
         abase[pi] = (((m * HD + dl) * HH + hl) * HW + wl) * VS + l4 * 16;
     }
-    // weights: fragment ci of K-step kidx = 1 KiB at wgt + (kidx*Cout_pad + n0 + wch*WCH*16 + ci*16)*32; lane = (row l15, k l4*8)
-    const half_t* wbase = p.wgt;
-    if (p.wslot) wbase += p.wofs[p.wslot[nb < p.N ? nb : p.N - 1]];         // per-sample weight set (uniform over the tile)
-    const half_t* wlane = wbase + ((long)(n0 + wch * WCH * 16) * 32 + l15 * 32 + l4 * 8);
-    const long wstep = (long)p.Cout_pad * 32;
     const int nck = (p.Cin + CK - 1) / CK;
     const int j0 = SK ? wave : 0;
     // cross-workgroup split-K (ConvParams::sk_out): blockIdx.z owns the channel chunks [cc_lo, cc_hi) and leaves raw partial sums
     int cc_lo = 0, cc_hi = nck;
     if (p.sk_out) { cc_lo = (int)(((long)nck * blockIdx.z) / gridDim.z); cc_hi = (int)(((long)nck * (blockIdx.z + 1)) / gridDim.z); }
+
+    // weights: fragment ci of K-step kidx = 1 KiB at wgt + (kidx*Cout_pad + n0 + wch*WCH*16 + ci*16)*32; lane = (row l15, k l4*8)
+    const half_t* wbase = p.wgt;
+    if (p.wslot) wbase += p.wofs[p.wslot[nb < p.N ? nb : p.N - 1]];         // per-sample weight set (uniform over the tile)
+    const half_t* wlane = wbase + ((long)(n0 + wch * WCH * 16) * 32 + l15 * 32 + l4 * 8);
+    const long wstep = (long)p.Cout_pad * 32;
 
     f4_t acc[WCH][WPX];
 #pragma unroll
@@ -247,13 +248,13 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             // prime the ring with this chunk's first steps before waiting on the halo: both latencies overlap
 #pragma unroll
             for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
-            if (cc > cc_lo) {
+            if (cc > cc_lo && !(p.hilo && cc == 1)) {      // hilo: weight chunk 1 reuses the staged hi halo
                 if (DB) {
                     __syncthreads();                       // chunk cc has landed in buffer (cc-cc_lo)&1; everyone left the other one
                     if (cc + 1 < cc_hi) stage_halo((cc + 1 - cc_lo) & 1, (cc + 1) * CK);
                 } else {
                     __syncthreads();
-                    stage_halo(0, cc * CK);
+                    stage_halo(0, (p.hilo ? 1 : cc) * CK);     // hilo: weight chunk 2 multiplies activation chunk 1 (lo)
                     __syncthreads();
                 }
             }
@@ -477,6 +478,19 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP, BN = WCH * 16 * WVC;
     constexpr int SLP = CK / 8 + 1, VS = SLP * 16;
     if (p.Cout_pad % BN != 0) { cs_set_error("conv_halo: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
+    {   // in-tensor element offsets are kept in 32 bits inside the kernel (halo piece offsets, epilogue addressing)
+        auto extent = [&](long sN, long sD, long sH, long sW, int C) -> long {
+            return (long)(p.N - 1) * sN + (long)(p.D - 1) * sD + (long)(p.H - 1) * sH + (long)(p.W - 1) * sW + C;
+        };
+        const long lim = 1L << 31;
+        if (extent(p.in_sN, p.in_sD, p.in_sH >> 0, p.in_sW, p.Cin) + (p.cg > 0 ? (long)(p.nchunks / p.cg) * p.in_sG : 0) >= lim ||
+            (p.out0.p && extent(p.out0.sN, p.out0.sD, p.out0.sH, p.out0.sW, p.Cout) >= lim) ||
+            (p.out1.p && extent(p.out1.sN, p.out1.sD, p.out1.sH, p.out1.sW, p.Cout) >= lim) ||
+            (p.res.p && extent(p.res.sN, p.res.sD, p.res.sH, p.res.sW, p.Cout) >= lim)) {
+            cs_set_error("conv_halo: a tensor of this launch spans 2^31 elements or more (32-bit in-tensor offsets)");
+            return -1;
+        }
+    }
     constexpr bool heavy_ok = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
     if ((!heavy_ok && p.act0 >= ACT_SIGMOID) || p.act1 >= ACT_SIGMOID) {
         cs_set_error("conv_halo: this tile configuration carries no sigmoid / GELU epilogue (act0 %d, act1 %d)", p.act0, p.act1);
@@ -500,6 +514,10 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
+    if (p.hilo && (ST == 0 || CK != 32 || nck != 3 || db || p.sk_out)) {
+        cs_set_error("conv_halo: the hi/lo split-precision mode needs a static-shape 32-channel kernel with three single-buffered chunks");
+        return -1;
+    }
     if (p.sk_out) {
         if (SK || p.sk_splits < 1 || p.sk_splits > nck || p.xcd_map == 2) { cs_set_error("conv_halo: bad split-K launch (%d splits, %d chunks)", p.sk_splits, nck); return -1; }
         grid.z = (unsigned)p.sk_splits;

@@ -99,7 +99,7 @@ struct cs_engine {
     half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
     float* vs[3]; half_t* va[2];
     float* sk_buf = nullptr; size_t sk_cap = 0;      // split-K partial sums (floats)
-    half_t* vsp[2];                        // split-precision conv inputs of R's GroupNorm blocks: [hi | lo | hi] per voxel
+    half_t* vsp[2];                        // split-precision conv inputs of R's GroupNorm blocks: [hi | lo] per voxel
     half_t *dm_comp, *dm_l[6], *dm_pre, *dm_pred;
     float *dm_logits, *dm_deform, *dm_occ;
     float *kpbuf;
@@ -567,15 +567,16 @@ int run_T(cs_engine* e, int B, const int* slots, int* cur, hipStream_t st)
 // G3d.forward (adaptive_modulate.py:721-733). x: fp32 vs[*cur] + fp16 va[0]; result fp32 in vs[*cur].
 // Split precision (default on; CANONSWAP_R_SPLIT=0 is the A/B knob): the two convs of a stage-3 block feed GroupNorms, which divide
 // by the std of the conv output - the fp16 rounding of operands there costs 1.5e-3 relative error on the refined volume (every
-// other stage: 1-4e-4) and sets the PSNR of the whole frame (50-57 dB depending on the frame).  With activations [hi | lo | hi]
-// and weights [W_hi | W_hi | W_lo] (three 32-channel chunks) the same fp16 MFMA kernel computes them to about 2^-21.
+// other stage: 1-4e-4) and sets the PSNR of the whole frame (50-57 dB depending on the frame).  With activations [hi | lo] and
+// weights [W_hi | W_lo | W_hi] (three 32-channel weight chunks, the hi halo staged once: ConvParams::hilo) the same fp16 MFMA kernel
+// computes W_hi x_hi + W_lo x_hi + W_hi x_lo, good to about 2^-21.
 bool r_split()
 {
     static const bool on = [] { const char* s = getenv("CANONSWAP_R_SPLIT"); return s ? atoi(s) != 0 : true; }();
     return on;
 }
 
-TDesc hwdc3_split(void* p) { return td(p, VOL * 3, 96, (long)FW * FD * 96, (long)FD * 96); }
+TDesc hwdc3_split(void* p) { return td(p, VOL * 2, 64, (long)FW * FD * 64, (long)FD * 64); }
 
 int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
 {
@@ -584,6 +585,7 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
     for (int i = 0; i < 3; ++i) {   // ResBlock3D_stage3_leak (util.py:528-544)
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
         ConvCall c1 = sp ? mk(blk[i].c1sp, e->vsp[0], hwdc3_split(nullptr), B, FD, FH, FW) : mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
+        c1.p.hilo = sp;
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
         c1.hcfg = cfg_v32();
         float* s1;
@@ -591,6 +593,7 @@ int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* 
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
                                                        sp ? e->vsp[1] : e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st, sp); }, "norm_act"));
         ConvCall c2 = sp ? mk(blk[i].c2sp, e->vsp[1], hwdc3_split(nullptr), B, FD, FH, FW) : mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
+        c2.p.hilo = sp;
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
         c2.hcfg = cfg_v32();
         float* s2;
@@ -831,7 +834,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     A(f_t0, B * 65536 * 64); A(f_t1, B * 65536 * 128); A(f_p0, B * 16384 * 128); A(f_t2, B * 16384 * 256); A(f_p1, B * 4096 * 256);
     for (int i = 0; i < 3; ++i) A(vs[i], B * VOL);
     for (int i = 0; i < 2; ++i) A(va[i], B * VOL);
-    for (int i = 0; i < 2; ++i) A(vsp[i], B * VOL * 3);
+    for (int i = 0; i < 2; ++i) A(vsp[i], B * VOL * 2);
     A(dm_comp, B * VOX * 4);
     static const long lsz[6] = {65536L * 144, 16L * 1024 * 128, 16L * 256 * 256, 16L * 64 * 512, 16L * 16 * 1024, 16L * 4 * 1024};
     for (int i = 0; i < 6; ++i) A(dm_l[i], B * lsz[i]);

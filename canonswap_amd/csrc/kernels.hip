@@ -490,16 +490,16 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
     }
     if (out32) *(float4*)(out32 + i) = make_float4(v[0], v[1], v[2], v[3]);
     if (out16 && !split) *(h4_t*)(out16 + i) = o16;
-    if (out16 && split) {      // split precision for the next conv: voxel-wise [hi(32) | lo(32) | hi(32)], hi + lo == value to 2^-22
+    if (out16 && split) {      // split precision for the next conv: voxel-wise [hi(32) | lo(32)], hi + lo == value to 2^-22
         h4_t lo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) lo[r] = (half_t)(v[r] - (float)o16[r]);     // split mode carries no second affine: o16 = fp16(v)
-        half_t* o = out16 + (i >> 5) * 96 + c;
-        *(h4_t*)o = o16; *(h4_t*)(o + 32) = lo; *(h4_t*)(o + 64) = o16;
+        half_t* o = out16 + (i >> 5) * 64 + c;
+        *(h4_t*)o = o16; *(h4_t*)(o + 32) = lo;
     }
 }
 
-// fp32 volume -> split-precision fp16 [hi | lo | hi] per voxel of 32 channels
+// fp32 volume -> split-precision fp16 [hi | lo] per voxel of 32 channels
 __global__ void __launch_bounds__(256) split16_kernel(const float* __restrict__ x, half_t* __restrict__ out, long total4)
 {
     const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(256) split16_kernel(const float* __restrict__ 
     h4_t hi, lo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hi[r] = (half_t)v[r]; lo[r] = (half_t)(v[r] - (float)hi[r]); }
-    half_t* o = out + (i >> 5) * 96 + (i & 31);
-    *(h4_t*)o = hi; *(h4_t*)(o + 32) = lo; *(h4_t*)(o + 64) = hi;
+    half_t* o = out + (i >> 5) * 64 + (i & 31);
+    *(h4_t*)o = hi; *(h4_t*)(o + 32) = lo;
 }
 
 int launch_split16(const float* x, half_t* out, long n, hipStream_t st)

@@ -180,13 +180,13 @@ def _pack_R(out, sd):
             p, n = f"{blk}.{i}", f"R.{name}.{i}"
             for c in ("1", "2"):
                 out[f"{n}.c{c}.w"] = pack_conv(sd[f"{p}.conv{c}.weight"], 32)
-                # split-precision variant [W_hi | W_hi | W_lo] over the input channels, for inputs stored [hi | lo | hi]: the
+                # split-precision variant [W_hi | W_lo | W_hi] over the input channels, for inputs stored [hi | lo]: the
                 # GroupNorm that follows each of these convs divides by the std of their output, and the fp16 rounding of
                 # operands there is what limits the whole frame's PSNR
                 w = np.asarray(sd[f"{p}.conv{c}.weight"], np.float32)
                 hi = w.astype(np.float16).astype(np.float32)
                 lo = (w - hi).astype(np.float16).astype(np.float32)
-                out[f"{n}.c{c}.sp.w"] = pack_conv(np.concatenate([hi, hi, lo], axis=1), 32)
+                out[f"{n}.c{c}.sp.w"] = pack_conv(np.concatenate([hi, lo, hi], axis=1), 32)    # chunks x [x_hi, x_hi, x_lo] (ConvParams::hilo)
                 out[f"{n}.c{c}.b"] = _f32(sd[f"{p}.conv{c}.bias"])
                 out[f"{n}.gn{c}.w"] = _f32(sd[f"{p}.gn{c}.weight"])
                 out[f"{n}.gn{c}.b"] = _f32(sd[f"{p}.gn{c}.bias"])
