@@ -93,30 +93,46 @@ _Pragma("unroll") \
     constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
     const bool ep_fetch = EP_PF && p.res.p != nullptr; \
     const int ep_rshift = (MODE == MODE_SPADE) ? p.res_shift : 0; \
+    /* Addressing.  A position of the tile is m = blk * 16 + l15 with blk = ep_wpx * EP_WPX + pi uniform over the wave; the tile's \
+       (w, h, d, n) are disjoint bit fields of m, so every coordinate - also after the >> of an up-sampled operand - is the sum of a \
+       lane part (bits of l15) and a block part (bits of blk), and every element offset (a linear form in the coordinates) is \
+       lane offset + block offset: the lane offsets are computed once per wave (VALU), the block offsets are scalar arithmetic. \
+       Offsets are 32-bit (launchers refuse tensors of 2^31 elements) and unsigned, which lets the loads / stores use the \
+       SGPR-base + VGPR-offset form. */ \
+    int ep_lw, ep_lh, ep_ld, ep_ln; \
+    { int t = l15; ep_lw = t & mW; t >>= p.lgTW; ep_lh = t & mH; t >>= p.lgTH; ep_ld = t & mD; t >>= p.lgTD; ep_ln = t; } \
+    const int ep_w0 = tw << p.lgTW, ep_h0 = th << p.lgTH, ep_d0 = td << p.lgTD, ep_nb = tn * (BM >> lgS); \
+    const int ep_rs = (MODE == MODE_SPADE) ? p.res_shift : 0; \
+    const unsigned ep_lane_res = (unsigned)((ep_nb + ep_ln) * (int)p.res.sN + (ep_d0 + ep_ld) * (int)p.res.sD + \
+                                            ((ep_h0 + ep_lh) >> ep_rs) * (int)p.res.sH + ((ep_w0 + ep_lw) >> ep_rs) * (int)p.res.sW); \
+    const unsigned ep_lane_o0 = (unsigned)((ep_nb + ep_ln) * (int)p.out0.sN + (ep_d0 + ep_ld) * (int)p.out0.sD + \
+                                           (ep_h0 + ep_lh) * (int)p.out0.sH + (ep_w0 + ep_lw) * (int)p.out0.sW); \
+    const unsigned ep_lane_o1 = (unsigned)((ep_nb + ep_ln) * (int)p.out1.sN + (ep_d0 + ep_ld) * (int)p.out1.sD + \
+                                           (ep_h0 + ep_lh) * (int)p.out1.sH + (ep_w0 + ep_lw) * (int)p.out1.sW); \
+    const unsigned ep_lane_ps = (unsigned)(((((ep_nb + ep_ln) * p.D + ep_d0 + ep_ld) * p.H + ep_h0 + ep_lh) * p.W + ep_w0 + ep_lw) * p.ps_stride); \
+    /* pixel shuffle: out[n][c][2h + i][2w + j], H2 = 2H, W2 = 2W */ \
+    const unsigned ep_lane_px = (unsigned)((((ep_nb + ep_ln) * 3) * 2 * p.H + 2 * (ep_h0 + ep_lh)) * 2 * p.W + 2 * (ep_w0 + ep_lw)); \
 _Pragma("unroll") \
     for (int pg = 0; pg < EP_WPX; pg += EP_G) { \
     ep_u4_t ep_raw[EP_G][EP_NCI]; float ep_ps[EP_G]; \
     if (EP_PF && (ep_fetch || p.pixscale)) { \
 _Pragma("unroll") \
         for (int g = 0; g < EP_G; ++g) { \
-            int m = ep_wpx * EP_WPX * 16 + (pg + g) * 16 + l15; \
-            const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
-            const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
-            const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD; \
-            const int n = tn * (BM >> lgS) + m; \
-            if (n >= p.N) continue; \
-            if (p.pixscale) ep_ps[g] = p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
+            int bw, bh, bd, bn; \
+            { int t = (ep_wpx * EP_WPX + pg + g) << 4; bw = t & mW; t >>= p.lgTW; bh = t & mH; t >>= p.lgTH; bd = t & mD; t >>= p.lgTD; bn = t; } \
+            if (ep_nb + ep_ln + bn >= p.N) continue; \
+            if (p.pixscale) ep_ps[g] = p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
             if (ep_fetch) { \
+                const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + \
+                                                            (bw >> ep_rs) * (int)p.res.sW); \
 _Pragma("unroll") \
                 for (int ci = 0; ci < WCH; ci += CSTEP) { \
                     const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
                     const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
                     if (cb >= p.Cout) continue; \
-                    const long xo = (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> ep_rshift) * p.res.sH + \
-                                    (long)(w >> ep_rshift) * p.res.sW + cb; \
-                    if (p.res_f32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + xo); \
+                    if (p.res_f32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + (xb + (unsigned)cb)); \
                     else { \
-                        const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + xo); \
+                        const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
                         ep_raw[g][(EP_PF ? ci / CSTEP : 0)][0] = q2[0]; ep_raw[g][(EP_PF ? ci / CSTEP : 0)][1] = q2[1]; \
                     } \
                 } \
@@ -128,14 +144,14 @@ _Pragma("unroll") \
     for (int g = 0; g < EP_G; ++g) { \
         const int pi = pg + g; \
         if (pi == 1) EP_TL(7); \
-        int m = ep_wpx * EP_WPX * 16 + pi * 16 + l15; \
-        const int w = (tw << p.lgTW) + (m & mW); m >>= p.lgTW; \
-        const int h = (th << p.lgTH) + (m & mH); m >>= p.lgTH; \
-        const int d = (td << p.lgTD) + (m & mD); m >>= p.lgTD; \
-        const int n = tn * (BM >> lgS) + m; \
-        if (n >= p.N) continue; \
+        int bw, bh, bd, bn; \
+        { int t = (ep_wpx * EP_WPX + pi) << 4; bw = t & mW; t >>= p.lgTW; bh = t & mH; t >>= p.lgTH; bd = t & mD; t >>= p.lgTD; bn = t; } \
+        if (ep_nb + ep_ln + bn >= p.N) continue; \
         float ps = 1.f; \
-        if (p.pixscale) ps = EP_PF ? ep_ps[g] : p.pixscale[((((long)n * p.D + d) * p.H + h) * p.W + w) * p.ps_stride]; \
+        if (p.pixscale) ps = EP_PF ? ep_ps[g] : p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
+        const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + (bw >> ep_rs) * (int)p.res.sW); \
+        const unsigned ob0 = ep_lane_o0 + (unsigned)(bn * (int)p.out0.sN + bd * (int)p.out0.sD + bh * (int)p.out0.sH + bw * (int)p.out0.sW); \
+        const unsigned ob1 = ep_lane_o1 + (unsigned)(bn * (int)p.out1.sN + bd * (int)p.out1.sD + bh * (int)p.out1.sH + bw * (int)p.out1.sW); \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
             const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
@@ -156,8 +172,7 @@ _Pragma("unroll") \
                         for (int r = 0; r < 4; ++r) rr[r] = (float)hx[r]; \
                     } \
                 } else { \
-                    load4(p.res, p.res_f32, (long)n * p.res.sN + (long)d * p.res.sD + (long)(h >> ep_rshift) * p.res.sH + \
-                                            (long)(w >> ep_rshift) * p.res.sW + cb, rr); \
+                    load4(p.res, p.res_f32, (long)(xb + (unsigned)cb), rr); \
                 } \
             } \
             float v[4]; \
@@ -182,8 +197,8 @@ _Pragma("unroll") \
                 const int c = cb >> 2; \
                 if (c < 3) { \
                     float* o = (float*)p.out0.p; \
-                    const long W2 = 2L * p.W, H2 = 2L * p.H; \
-                    const long base = (((long)n * 3 + c) * H2 + 2 * h) * W2 + 2 * w; \
+                    const unsigned W2 = 2u * (unsigned)p.W, H2 = 2u * (unsigned)p.H; \
+                    const unsigned base = ep_lane_px + ((unsigned)(bn * 3 + c) * H2 + 2u * (unsigned)bh) * W2 + 2u * (unsigned)bw; \
                     *(float2*)(o + base) = make_float2(v[0], v[1]); \
                     *(float2*)(o + base + W2) = make_float2(v[2], v[3]); \
                 } \
@@ -197,8 +212,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \
-            if (p.out0.p) \
-                store4(p.out0, p.out0_f32, (long)n * p.out0.sN + (long)d * p.out0.sD + (long)h * p.out0.sH + (long)w * p.out0.sW + cb, v); \
+            if (p.out0.p) store4(p.out0, p.out0_f32, (long)(ob0 + (unsigned)cb), v); \
             if (EP_STAT) { /* statistics of the values as stored (fp16-rounded when out0 is fp16) */ \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
@@ -213,7 +227,7 @@ _Pragma("unroll") \
                     const float a = v[r] * ((const float*)&ep_s2[ci])[r] + ((const float*)&ep_t2[ci])[r]; \
                     u[r] = lin_act(a, ep_sl1); \
                 } \
-                store4(p.out1, 0, (long)n * p.out1.sN + (long)d * p.out1.sD + (long)h * p.out1.sH + (long)w * p.out1.sW + cb, u); \
+                store4(p.out1, 0, (long)(ob1 + (unsigned)cb), u); \
             } \
         } \
     } \

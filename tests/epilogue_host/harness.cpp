@@ -1,0 +1,141 @@
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <cstdint>
+#define __device__
+#define __forceinline__ inline
+struct float4 { float x, y, z, w; }; struct float2 { float x, y; };
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return {a, b}; }
+#define __expf expf
+static inline float __shfl_xor(float a, int, int) { return a; }
+#define hipStream_t void*
+#include "common_stub.h"
+#include EPH
+
+static uint32_t hsh(uint32_t a) { a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16; return a; }
+static float rnd(uint32_t a) { return (float)(hsh(a) % 20001) / 10000.f - 1.f; }
+
+template <int WPX, int WCH, int WVP, int WVC, int MODE, bool EP_HEAVY>
+void run(const ConvParams& p, int BM)
+{
+    constexpr int BN = WCH * 16 * WVC;
+    const int ntiles = p.nTW * p.nTH * p.nTD * p.nTN;
+    for (int cb = 0; cb < p.Cout_pad / BN; ++cb)
+    for (int tile = 0; tile < ntiles; ++tile)
+    for (int wave = 0; wave < 4; ++wave)
+    for (int lane = 0; lane < 64; ++lane) {
+        const int tile_lin = tile;
+        int t = tile_lin;
+        const int tw = t % p.nTW; t /= p.nTW; const int th = t % p.nTH; t /= p.nTH; const int td = t % p.nTD; t /= p.nTD; const int tn = t;
+        const int n0 = cb * BN;
+        const int lgS = p.lgTW + p.lgTH + p.lgTD;
+        const int mW = (1 << p.lgTW) - 1, mH = (1 << p.lgTH) - 1, mD = (1 << p.lgTD) - 1;
+        const int wpx = wave % WVP, wch = wave / WVP;
+        const int l15 = lane & 15, l4 = lane >> 4;
+        f4_t acc[WCH][WPX];
+        for (int ci = 0; ci < WCH; ++ci) for (int pi = 0; pi < WPX; ++pi) for (int r = 0; r < 4; ++r)
+            acc[ci][pi][r] = rnd(((tile * 4 + wave) * 64 + lane) * 97 + (ci * WPX + pi) * 4 + r + cb * 7919);
+        constexpr int EP_WPX = WPX;
+        const int ep_wpx = wpx;
+        auto& ep_acc = acc;
+        CONV_EPILOGUE()
+    }
+}
+
+static std::vector<float> F(size_t n, uint32_t seed) { std::vector<float> v(n); for (size_t i = 0; i < n; ++i) v[i] = rnd(seed + (uint32_t)i); return v; }
+static std::vector<half_t> H(size_t n, uint32_t seed) { std::vector<half_t> v(n); for (size_t i = 0; i < n; ++i) v[i] = (half_t)rnd(seed + (uint32_t)i); return v; }
+static uint64_t crc(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; uint64_t h = 1469598103934665603ULL; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ULL; } return h; }
+
+static void tile_of(ConvParams& p, int BM, int tw, int th) {
+    int td = BM / (tw * th); if (td > p.D) td = p.D; int tn = BM / (tw * th * td);
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    p.lgTW = lg(tw); p.lgTH = lg(th); p.lgTD = lg(td); p.nTW = p.W / tw; p.nTH = p.H / th; p.nTD = p.D / td; p.nTN = (p.N + tn - 1) / tn;
+}
+
+int main()
+{
+    // case 1: 2-D 16x8 tile, 128x128 STD, f32 residual, out1 with affine, pixscale, Cout 200 of 256 (ragged channels)
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 3; p.D = 1; p.H = 16; p.W = 32; p.Cout = 200; p.Cout_pad = 256; tile_of(p, 128, 16, 8);
+        const size_t P = (size_t)p.N * p.H * p.W;
+        auto res = F(P * 256, 1), ps = F(P * 4, 2), bias = F(256, 3), s2 = F(256, 4), t2 = F(256, 5);
+        std::vector<float> out0(P * 300, -9.f); std::vector<half_t> out1(P * 256, (half_t)-9.f);
+        p.res = TDesc{res.data(), (long)p.H * p.W * 256, 0, (long)p.W * 256, 256}; p.res_f32 = 1;
+        p.out0 = TDesc{out0.data(), (long)p.H * p.W * 300, 0, (long)p.W * 300, 300}; p.out0_f32 = 1;
+        p.out1 = TDesc{out1.data(), (long)p.H * p.W * 256, 0, (long)p.W * 256, 256};
+        p.pixscale = ps.data(); p.ps_stride = 4; p.bias = bias.data(); p.s2 = s2.data(); p.t2 = t2.data(); p.act0 = ACT_LRELU; p.slope0 = 0.2f; p.act1 = ACT_RELU;
+        run<8, 2, 1, 4, MODE_STD, false>(p, 128);
+        printf("case1 %016llx %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 4), (unsigned long long)crc(out1.data(), out1.size() * 2));
+    }
+    // case 2: volume 4x4x16 tile (256 positions), 256x32, f32 residual, hwdc strides, N = 2
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 16; p.H = 8; p.W = 8; p.Cout = 32; p.Cout_pad = 32; tile_of(p, 256, 4, 4);
+        const size_t V = (size_t)p.N * p.H * p.W * p.D * 32;
+        auto res = F(V, 11), bias = F(32, 12); std::vector<float> out0(V, -9.f); std::vector<half_t> out1(V, (half_t)-9.f);
+        TDesc d{nullptr, (long)p.H * p.W * p.D * 32, 32, (long)p.W * p.D * 32, (long)p.D * 32};
+        p.res = d; p.res.p = res.data(); p.res_f32 = 1; p.out0 = d; p.out0.p = out0.data(); p.out0_f32 = 1; p.out1 = d; p.out1.p = out1.data();
+        p.bias = bias.data(); p.ps_stride = 1; p.act1 = ACT_RELU;
+        std::vector<float> st((size_t)p.N * 4 * 4 * 32 * 2 * 8, -9.f); p.stat_out = st.data();
+        run<4, 2, 4, 1, MODE_STDSTAT, false>(p, 256);
+        printf("case2 %016llx %016llx %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 4), (unsigned long long)crc(out1.data(), out1.size() * 2), (unsigned long long)crc(st.data(), st.size() * 4));
+    }
+    // case 3: SPADE with up-sampled x (res_shift 1), f16 x, 128x128
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 1; p.H = 16; p.W = 16; p.Cout = 64; p.Cout_pad = 128; tile_of(p, 128, 16, 8);
+        const size_t P = (size_t)p.N * p.H * p.W, Px = (size_t)p.N * 8 * 8;
+        auto x = H(Px * 64, 21); auto bias = F(64, 22), bias2 = F(64, 23), stats = F(p.N * 64 * 2, 24);
+        std::vector<half_t> out0(P * 64, (half_t)-9.f);
+        p.res = TDesc{x.data(), 8L * 8 * 64, 0, 8L * 64, 64}; p.res_f32 = 0; p.res_shift = 1;
+        p.out0 = TDesc{out0.data(), (long)p.H * p.W * 64, 0, (long)p.W * 64, 64};
+        p.bias = bias.data(); p.bias2 = bias2.data(); p.stats = stats.data(); p.act0 = ACT_LRELU; p.slope0 = 0.2f; p.ps_stride = 1;
+        run<8, 2, 1, 4, MODE_SPADE, false>(p, 128);
+        printf("case3 %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 2));
+    }
+    // case 4: T blend 128x256, pixscale stride 4, f32 residual + outputs
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 1; p.H = 16; p.W = 16; p.Cout = 128; p.Cout_pad = 256; tile_of(p, 128, 16, 8);
+        const size_t P = (size_t)p.N * p.H * p.W;
+        auto res = F(P * 128, 31), ps = F(P * 4, 32), bias = F(128, 33);
+        std::vector<float> out0(P * 128, -9.f); std::vector<half_t> out1(P * 128, (half_t)-9.f);
+        TDesc d{nullptr, (long)p.H * p.W * 128, 0, (long)p.W * 128, 128};
+        p.res = d; p.res.p = res.data(); p.res_f32 = 1; p.out0 = d; p.out0.p = out0.data(); p.out0_f32 = 1; p.out1 = d; p.out1.p = out1.data();
+        p.pixscale = ps.data(); p.ps_stride = 4; p.bias = bias.data(); p.act0 = ACT_NONE;
+        run<8, 4, 1, 4, MODE_TBLEND, false>(p, 128);
+        printf("case4 %016llx %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 4), (unsigned long long)crc(out1.data(), out1.size() * 2));
+    }
+    // case 5: pixel shuffle + sigmoid, 256x16
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 1; p.H = 16; p.W = 16; p.Cout = 16; p.Cout_pad = 16; tile_of(p, 256, 16, 16);
+        auto bias = F(16, 41); std::vector<float> img((size_t)p.N * 3 * 32 * 32, -9.f);
+        p.out0 = TDesc{img.data(), 0, 0, 0, 0}; p.out0_f32 = 1; p.bias = bias.data(); p.act0 = ACT_SIGMOID; p.ps_stride = 1;
+        run<4, 1, 4, 1, MODE_PIXSHUF, true>(p, 256);
+        printf("case5 %016llx\n", (unsigned long long)crc(img.data(), img.size() * 4));
+    }
+    // case 6: tiny spatial (2x2x16 = 64 positions per sample, two samples per 128-position tile), odd batch, mask-like 2x8x8 tile too
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 3; p.D = 16; p.H = 2; p.W = 2; p.Cout = 128; p.Cout_pad = 128; tile_of(p, 128, 2, 2);
+        const size_t P = (size_t)p.N * p.D * p.H * p.W;
+        auto res = H(P * 128, 51); auto bias = F(128, 52); std::vector<half_t> out0(P * 160, (half_t)-9.f);
+        p.res = TDesc{res.data(), (long)p.D * p.H * p.W * 128, (long)p.H * p.W * 128, (long)p.W * 128, 128}; p.res_f32 = 0;
+        p.out0 = TDesc{out0.data(), (long)p.D * p.H * p.W * 160, (long)p.H * p.W * 160, (long)p.W * 160, 160};
+        p.bias = bias.data(); p.act0 = ACT_RELU; p.ps_stride = 1;
+        run<8, 2, 1, 4, MODE_STD, false>(p, 128);
+        printf("case6 %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 2));
+        ConvParams q; memset(&q, 0, sizeof q);
+        q.N = 2; q.D = 16; q.H = 16; q.W = 4; q.Cout = 160; q.Cout_pad = 160; tile_of(q, 128, 2, 8);
+        const size_t Q = (size_t)q.N * q.D * q.H * q.W; std::vector<float> o(Q * 160, -9.f);
+        q.out0 = TDesc{o.data(), (long)q.D * q.H * q.W * 160, (long)q.H * q.W * 160, (long)q.W * 160, 160}; q.out0_f32 = 1; q.ps_stride = 1;
+        run<4, 5, 2, 2, MODE_STD, false>(q, 128);
+        printf("case6b %016llx\n", (unsigned long long)crc(o.data(), o.size() * 4));
+    }
+    return 0;
+}

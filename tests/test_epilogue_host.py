@@ -1,0 +1,29 @@
+"""The shared conv epilogue (canonswap_amd/csrc/conv_epilogue.h) executed on the HOST: tests/epilogue_host/harness.cpp emulates
+the lanes of a workgroup one by one over whole tensors (2-D / volume / tiny-spatial tiles, ragged channels, odd batches, fp32 and
+fp16 residuals, second output, per-position scale, SPADE with an up-sampled operand, T blend, pixel shuffle, statistics) and
+prints a checksum per case.  tests/epilogue_host/expected.txt holds the checksums of the version whose results the GPU parity
+tests validated, so any later edit of the macro (addressing, prefetch order, activation forms) that changes a single stored bit
+shows up here without a GPU."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests", "epilogue_host")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang (ext_vector_type, _Float16)")
+def test_epilogue_macro_on_host(tmp_path):
+    csrc = os.path.join(ROOT, "canonswap_amd", "csrc")
+    common = open(os.path.join(csrc, "common.h")).read().replace("#include <hip/hip_runtime.h>", "")
+    (tmp_path / "common_stub.h").write_text(common[: common.index("#define CS_CHECK_HIP")])
+    (tmp_path / "ep.h").write_text(open(os.path.join(csrc, "conv_epilogue.h")).read().replace('#include "common.h"', ""))
+    shutil.copy(os.path.join(HERE, "harness.cpp"), tmp_path / "h.cpp")
+    exe = str(tmp_path / "h")
+    subprocess.run([CLANG, "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-everything", '-DEPH="ep.h"', "h.cpp", "-o", exe],
+                   cwd=tmp_path, check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(HERE, "expected.txt")).read()
