@@ -131,6 +131,7 @@ int launch_norm_act(const float* y, const float* stats, const float* gamma, cons
                     int act2, float slope2, int N, long per_n, hipStream_t st, int split = 0);
 int launch_split16(const float* x, half_t* out, long n, hipStream_t st);
 int launch_splitk_finish(const ConvParams& p, hipStream_t st);
+int launch_absmax16(const half_t* x, TDesc t, int N, int D, int H, int W, int C, unsigned* slot, hipStream_t st);
 int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,
                          int N, int C, int D, int H, int W, hipStream_t st);
 int launch_hwdc_to_ncdhw(const float* in, float* out, int N, int C, int D, int H, int W, hipStream_t st);

@@ -112,7 +112,8 @@ struct cs_engine {
 
     // ---- profiling
     bool prof = false;
-    struct Rec { int fam; hipEvent_t a, b; std::string label; double flops; };
+    struct Rec { int fam; hipEvent_t a, b; std::string label; double flops; int amax_slot; };
+    unsigned* amax_dev = nullptr; int amax_n = 0;          // CANONSWAP_AMAX=1: per-launch |max| of the fp16 outputs of a profiled step
     std::vector<Rec> recs;
     std::vector<hipEvent_t> evpool;
     size_t evnext = 0;
@@ -130,7 +131,7 @@ struct cs_engine {
         hipEventRecord(a, st);
         int r = f();
         hipEventRecord(b, st);
-        recs.push_back({fam, a, b, label, fl});
+        recs.push_back({fam, a, b, label, fl, -1});
         return r;
     }
     template <class T> int alloc(T** p, size_t n)
@@ -283,6 +284,8 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     return CFG_H_128x16;
 }
 
+int amax_after(cs_engine* e, const struct ConvCall& c, hipStream_t st);
+
 // Launch one convolution. Default path: conv_halo (LDS-staged input patch, register-streamed weights);
 // conv_igemm handles the depth-collapsing occlusion conv (and everything when CANONSWAP_NO_HALO is set).
 int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
@@ -330,7 +333,8 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
                 }
             }
         }
-        return e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl);
+        TRY(e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl));
+        return amax_after(e, c, st);
     }
     if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
@@ -341,6 +345,25 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
 }
 
 float* stats_slot(cs_engine* e);
+
+// debug knob CANONSWAP_AMAX=1 (profiled steps only): largest |value| of the fp16 tensors this conv stored
+int amax_after(cs_engine* e, const ConvCall& c, hipStream_t st)
+{
+    static const bool on = [] { const char* s = getenv("CANONSWAP_AMAX"); return s && atoi(s) != 0; }();
+    if (!on || !e->prof || e->recs.empty()) return 0;
+    if (!e->amax_dev) { if (e->alloc(&e->amax_dev, (size_t)4096)) return -1; }
+    if (e->amax_n >= 4096) return 0;
+    const ConvParams& p = c.p;
+    const bool o0 = p.out0.p && !p.out0_f32 && c.mode != MODE_PIXSHUF, o1 = p.out1.p != nullptr;
+    if (!o0 && !o1) return 0;
+    const int slot = e->amax_n++;
+    hipError_t r = hipMemsetAsync(e->amax_dev + slot, 0, sizeof(unsigned), st);
+    if (r != hipSuccess) { cs_set_error("amax memset: %s", hipGetErrorString(r)); return -1; }
+    if (o0) TRY(launch_absmax16((const half_t*)p.out0.p, p.out0, p.N, p.D, p.H, p.W, p.Cout, e->amax_dev + slot, st));
+    if (o1) TRY(launch_absmax16((const half_t*)p.out1.p, p.out1, p.N, p.D, p.H, p.W, p.Cout, e->amax_dev + slot, st));
+    for (auto it = e->recs.rbegin(); it != e->recs.rend(); ++it) if (it->fam == 0) { it->amax_slot = slot; break; }
+    return 0;
+}
 
 // Convolution whose epilogue also emits the Instance/GroupNorm partial sums of its stored output; returns the finished
 // (mean, rstd) slot. P = positions per sample.
@@ -1308,7 +1331,7 @@ extern "C" int cs_paste_back(cs_engine* e, const uint8_t* crop, const float* mas
 extern "C" int cs_profile_begin(cs_engine* e)
 {
     if (!e) { cs_set_error("null engine"); return -1; }
-    e->prof = true; e->recs.clear(); e->evnext = 0; e->flops = 0; e->flops_exec = 0;
+    e->prof = true; e->recs.clear(); e->evnext = 0; e->flops = 0; e->flops_exec = 0; e->amax_n = 0;
     return 0;
 }
 
@@ -1319,12 +1342,19 @@ extern "C" int cs_profile_end(cs_engine* e, double ms[3], long counts[3], double
     ms[0] = ms[1] = ms[2] = 0; counts[0] = counts[1] = counts[2] = 0;
     FILE* csv = nullptr;
     if (const char* path = getenv("CANONSWAP_PROFILE_CSV")) csv = fopen(path, "w");
-    if (csv) fprintf(csv, "family,label,ms,gflop\n");
+    std::vector<unsigned> amax((size_t)e->amax_n);
+    if (e->amax_n) CS_CHECK_HIP(hipMemcpy(amax.data(), e->amax_dev, sizeof(unsigned) * e->amax_n, hipMemcpyDeviceToHost));
+    if (csv) fprintf(csv, e->amax_n ? "family,label,ms,gflop,fp16_amax\n" : "family,label,ms,gflop\n");
     for (auto& r : e->recs) {
         float t = 0;
         CS_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
         ms[r.fam] += t; counts[r.fam]++;
-        if (csv) fprintf(csv, "%d,%s,%.5f,%.4f\n", r.fam, r.label.c_str(), t, r.flops / 1e9);
+        if (csv && e->amax_n) {
+            float am = -1.f;
+            if (r.amax_slot >= 0) memcpy(&am, &amax[r.amax_slot], 4);
+            if (am >= 0) fprintf(csv, "%d,%s,%.5f,%.4f,%.6g\n", r.fam, r.label.c_str(), t, r.flops / 1e9, am);
+            else fprintf(csv, "%d,%s,%.5f,%.4f,\n", r.fam, r.label.c_str(), t, r.flops / 1e9);
+        } else if (csv) fprintf(csv, "%d,%s,%.5f,%.4f\n", r.fam, r.label.c_str(), t, r.flops / 1e9);
     }
     if (csv) fclose(csv);
     if (flops) *flops = e->flops;

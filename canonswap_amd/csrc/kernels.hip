@@ -815,3 +815,34 @@ int launch_splitk_finish(const ConvParams& p, hipStream_t st)
     LAUNCH_CHECK("splitk_finish");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// debug: largest magnitude of an fp16 channels-last tensor view (CANONSWAP_AMAX=1 in a profiled step: how close every layer's
+// stored activations come to the fp16 range limit 65504).  slot: float bits, maximum by integer compare (values are >= 0)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) absmax16_kernel(const half_t* __restrict__ x, TDesc t, int N, int D, int H, int W, int C, unsigned* slot)
+{
+    const long npos = (long)N * D * H * W;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npos * (C / 4); i += (long)gridDim.x * 256) {
+        long pos = i / (C / 4);
+        const int c = (int)(i % (C / 4)) * 4;
+        const int w = (int)(pos % W); pos /= W;
+        const int h = (int)(pos % H); pos /= H;
+        const int d = (int)(pos % D); pos /= D;
+        const h4_t v = *(const h4_t*)(x + pos * t.sN + (long)d * t.sD + (long)h * t.sH + (long)w * t.sW + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float a = fabsf((float)v[r]); m = (a == a) ? fmaxf(m, a) : INFINITY; }     // NaN counts as overflow
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+
+int launch_absmax16(const half_t* x, TDesc t, int N, int D, int H, int W, int C, unsigned* slot, hipStream_t st)
+{
+    if (C % 4) return 0;
+    hipLaunchKernelGGL(absmax16_kernel, dim3(512), dim3(256), 0, st, x, t, N, D, H, W, C, slot);
+    LAUNCH_CHECK("absmax16");
+    return 0;
+}
