@@ -51,7 +51,9 @@ __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, con
 // EP_HEAVY (constexpr bool, in scope): this instantiation also carries sigmoid / GELU for act0 (launchers refuse those activations
 // on the others); act1 is always one of none / ReLU / LeakyReLU.
 // Expects in scope: p, ep_acc[WCH][EP_WPX] (f4_t), ep_wpx (position-block index of this wave), EP_WPX, n0, tw, th, td, tn,
-// lgS, mW, mH, mD, wch, l15, l4, tile_lin (linear index of the position tile) and the template constants WCH, BM, MODE.
+// lgTW, lgTH, lgTD, lgS, mW, mH, mD (the tile decomposition: compile-time constants in the static-shape kernels, which turns the
+// per-block coordinates below into constants), wch, l15, l4, tile_lin (linear index of the position tile) and the template constants
+// WCH, BM, MODE.
 #define CONV_EPILOGUE() \
     constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
     /* per-channel constants of this lane's 4 channels, loaded once (16-byte loads), not once per position block */ \
@@ -100,8 +102,8 @@ _Pragma("unroll") \
        Offsets are 32-bit (launchers refuse tensors of 2^31 elements) and unsigned, which lets the loads / stores use the \
        SGPR-base + VGPR-offset form. */ \
     int ep_lw, ep_lh, ep_ld, ep_ln; \
-    { int t = l15; ep_lw = t & mW; t >>= p.lgTW; ep_lh = t & mH; t >>= p.lgTH; ep_ld = t & mD; t >>= p.lgTD; ep_ln = t; } \
-    const int ep_w0 = tw << p.lgTW, ep_h0 = th << p.lgTH, ep_d0 = td << p.lgTD, ep_nb = tn * (BM >> lgS); \
+    { int t = l15; ep_lw = t & mW; t >>= lgTW; ep_lh = t & mH; t >>= lgTH; ep_ld = t & mD; t >>= lgTD; ep_ln = t; } \
+    const int ep_w0 = tw << lgTW, ep_h0 = th << lgTH, ep_d0 = td << lgTD, ep_nb = tn * (BM >> lgS); \
     const int ep_rs = (MODE == MODE_SPADE) ? p.res_shift : 0; \
     const unsigned ep_lane_res = (unsigned)((ep_nb + ep_ln) * (int)p.res.sN + (ep_d0 + ep_ld) * (int)p.res.sD + \
                                             ((ep_h0 + ep_lh) >> ep_rs) * (int)p.res.sH + ((ep_w0 + ep_lw) >> ep_rs) * (int)p.res.sW); \
@@ -119,7 +121,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int g = 0; g < EP_G; ++g) { \
             int bw, bh, bd, bn; \
-            { int t = (ep_wpx * EP_WPX + pg + g) << 4; bw = t & mW; t >>= p.lgTW; bh = t & mH; t >>= p.lgTH; bd = t & mD; t >>= p.lgTD; bn = t; } \
+            { int t = (ep_wpx * EP_WPX + pg + g) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
             if (ep_nb + ep_ln + bn >= p.N) continue; \
             if (p.pixscale) ep_ps[g] = p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
             if (ep_fetch) { \
@@ -145,7 +147,7 @@ _Pragma("unroll") \
         const int pi = pg + g; \
         if (pi == 1) EP_TL(7); \
         int bw, bh, bd, bn; \
-        { int t = (ep_wpx * EP_WPX + pi) << 4; bw = t & mW; t >>= p.lgTW; bh = t & mH; t >>= p.lgTH; bd = t & mD; t >>= p.lgTD; bn = t; } \
+        { int t = (ep_wpx * EP_WPX + pi) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
         if (ep_nb + ep_ln + bn >= p.N) continue; \
         float ps = 1.f; \
         if (p.pixscale) ps = EP_PF ? ep_ps[g] : p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \

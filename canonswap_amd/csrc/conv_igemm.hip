@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
     const int td = t % p.nTD; t /= p.nTD;
     const int tn = t;
     const int n0 = blockIdx.y * BN;
+    const int lgTW = p.lgTW, lgTH = p.lgTH, lgTD = p.lgTD;
     const int lgS = p.lgTW + p.lgTH + p.lgTD;
     const int mW = (1 << p.lgTW) - 1, mH = (1 << p.lgTH) - 1, mD = (1 << p.lgTD) - 1;
 

@@ -31,6 +31,7 @@ void run(const ConvParams& p, int BM)
         int t = tile_lin;
         const int tw = t % p.nTW; t /= p.nTW; const int th = t % p.nTH; t /= p.nTH; const int td = t % p.nTD; t /= p.nTD; const int tn = t;
         const int n0 = cb * BN;
+        const int lgTW = p.lgTW, lgTH = p.lgTH, lgTD = p.lgTD;
         const int lgS = p.lgTW + p.lgTH + p.lgTD;
         const int mW = (1 << p.lgTW) - 1, mH = (1 << p.lgTH) - 1, mD = (1 << p.lgTD) - 1;
         const int wpx = wave % WVP, wch = wave / WVP;
