@@ -36,6 +36,8 @@ __device__ __forceinline__ void load4(const TDesc& t, int is_f32, long off, floa
     }
 }
 
+// Ablation build (tools/build_variant.py, not the product): -DCS_EP_NOSTORE puts every epilogue store behind a runtime condition
+// that is never true (what the stores cost: profiles/r02_store_ablation.txt).
 __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, const float v[4])
 {
     if (is_f32) {
@@ -48,20 +50,128 @@ __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, con
 }
 
 
+__device__ __forceinline__ void store8(const TDesc& t, int is_f32, long off, const float a[4], const float b[4])
+{
+    if (is_f32) {
+        *(float4*)((float*)t.p + off) = make_float4(a[0], a[1], a[2], a[3]);
+        *(float4*)((float*)t.p + off + 4) = make_float4(b[0], b[1], b[2], b[3]);
+    } else {
+        h8_t x;
+        x[0] = (half_t)a[0]; x[1] = (half_t)a[1]; x[2] = (half_t)a[2]; x[3] = (half_t)a[3];
+        x[4] = (half_t)b[0]; x[5] = (half_t)b[1]; x[6] = (half_t)b[2]; x[7] = (half_t)b[3];
+        *(h8_t*)((half_t*)t.p + off) = x;
+    }
+}
+
+// Channel pairing (EP_PAIR).  An MFMA output fragment gives a lane 4 consecutive rows (l4 * 4 + r), i.e. 4 consecutive output
+// channels: 8-byte fp16 stores, 16 separate 32-byte pieces per store instruction.  Which packed weight row a lane feeds into row i
+// of a fragment is free, so kernels with an even number of output fragments per wave permute the rows of each fragment PAIR:
+//   EP_PAIR 1 (one output per fragment, WCH even):      fragment 2q + h, row 4a + j  <-  row 32q + 8a + 4h + j of the wave's rows
+//   EP_PAIR 2 (T blend / SPADE: fragments come as (plain, modulated) / (gamma, beta) twins over 16-row blocks, WCH % 4 == 0):
+//              fragment 4q + 2h + t, row 4a + j  <-  twin t of output channel 32q + 8a + 4h + j of the wave's output channels
+// A lane then owns 8 consecutive output channels per pair: ONE 16-byte fp16 store / residual load (two adjacent 16-byte ones for
+// fp32) - half the store instructions, which is what the epilogue's store tail is bound by (MI355X_MICROARCH: store-issue-bound;
+// profiles/r02_store_ablation.txt).  The weight fetch of a fragment still covers 8 whole 128-byte lines.
+// ep_frag_row / ep_lane_row: the conv kernel's weight addressing; ep_chan: first of the 4 channels of (fragment ci, row group l4).
+__device__ __forceinline__ constexpr int ep_frag_row(int pair, int ci)
+{
+    return pair == 1 ? (ci >> 1) * 32 + (ci & 1) * 4 : pair == 2 ? (ci >> 2) * 64 + ((ci >> 1) & 1) * 4 + (ci & 1) * 16 : ci * 16;
+}
+__device__ __forceinline__ constexpr int ep_lane_row(int pair, int i)
+{
+    const int c = (i >> 2) * 8 + (i & 3);
+    return pair == 1 ? c : pair == 2 ? (c >> 4) * 32 + (c & 15) : i;
+}
+__device__ __forceinline__ constexpr int ep_chan(int pair, int cstep, int wave_row0, int ci, int l4)
+{
+    if (pair == 1) return wave_row0 + (ci >> 1) * 32 + l4 * 8 + (ci & 1) * 4;
+    if (pair == 2) return wave_row0 / 2 + (ci >> 2) * 32 + l4 * 8 + ((ci >> 1) & 1) * 4;
+    const int pb = wave_row0 / 16 + ci;
+    return (cstep == 2 ? (pb >> 1) : pb) * 16 + l4 * 4;
+}
+__device__ __forceinline__ constexpr bool ep_second(int pair, int ci) { return pair == 1 ? (ci & 1) != 0 : pair == 2 ? ((ci >> 1) & 1) != 0 : false; }
+// 8 fp16 channels at a multiple-of-8 channel offset are 16-byte aligned in this view
+__device__ __forceinline__ bool ep_al8(const TDesc& t)
+{
+    return (((unsigned long long)t.p & 15ull) == 0) && (((t.sN | t.sD | t.sH | t.sW) & 7) == 0);
+}
+// EP_PAIR of a kernel instantiation
+__device__ __forceinline__ constexpr int ep_pair_of(int mode, int wch)
+{
+    return (mode == MODE_PIXSHUF) ? 0 : (mode == MODE_TBLEND || mode == MODE_SPADE) ? (wch % 4 == 0 ? 2 : 0) : (wch % 2 == 0 ? 1 : 0);
+}
+
 // EP_HEAVY (constexpr bool, in scope): this instantiation also carries sigmoid / GELU for act0 (launchers refuse those activations
 // on the others); act1 is always one of none / ReLU / LeakyReLU.
 // Expects in scope: p, ep_acc[WCH][EP_WPX] (f4_t), ep_wpx (position-block index of this wave), EP_WPX, n0, tw, th, td, tn,
 // lgTW, lgTH, lgTD, lgS, mW, mH, mD (the tile decomposition: compile-time constants in the static-shape kernels, which turns the
 // per-block coordinates below into constants), wch, l15, l4, tile_lin (linear index of the position tile) and the template constants
-// WCH, BM, MODE.
+// WCH, BM, MODE, EP_EARLY (+ ep_xpre from CONV_EPILOGUE_EARLY_FETCH; false elsewhere), EP_PAIR (ep_pair_of(MODE, WCH) where the kernel permutes its weight rows accordingly, else 0).
+#if defined(CS_EP_NOSTORE)
+#define EP_STORE_COND && (p.N < 0)
+#else
+#define EP_STORE_COND
+#endif
+// SPADE kernels fetch the tensor they modulate (x, fp16) for the wave's WHOLE tile at kernel start, where the round trip hides behind
+// the first halo wait, instead of after the main loop where every wave of the CU would sit through it at the same time (the
+// workgroups of a CU run in lock step; profiles/r02_timeline_*.txt: "epi first block").  16 more live registers in the main loop:
+// only where the kernel has them to spare (EP_EARLY, set by the kernel).  Same addresses / validity rules as CONV_EPILOGUE's fetch
+// round.  Expects the kernel's tile decomposition in scope (see CONV_EPILOGUE) and EP_WPX0 = position blocks per wave, ep_wpx0 = the
+// wave's block index; defines ep_xpre.
+#define CONV_EPILOGUE_EARLY_FETCH() \
+    ep_u2_t ep_xpre[EP_EARLY ? EP_WPX0 : 1][EP_EARLY ? (WCH + 1) / 2 : 1]; \
+    if constexpr (EP_EARLY) { \
+        int xlw, xlh, xld, xln; \
+        { int t = l15; xlw = t & mW; t >>= lgTW; xlh = t & mH; t >>= lgTH; xld = t & mD; t >>= lgTD; xln = t; } \
+        const int xrs = p.res_shift, xnb = tn * (BM >> lgS); \
+        const unsigned xlane = (unsigned)((xnb + xln) * (int)p.res.sN + ((td << lgTD) + xld) * (int)p.res.sD + \
+                                          (((th << lgTH) + xlh) >> xrs) * (int)p.res.sH + (((tw << lgTW) + xlw) >> xrs) * (int)p.res.sW); \
+_Pragma("unroll") \
+        for (int pi = 0; pi < EP_WPX0; ++pi) { \
+            int bw, bh, bd, bn; \
+            { int t = (ep_wpx0 * EP_WPX0 + pi) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
+            const unsigned xb = xlane + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> xrs) * (int)p.res.sH + (bw >> xrs) * (int)p.res.sW); \
+_Pragma("unroll") \
+            for (int ci = 0; ci < WCH; ci += 2) { \
+                const int cb = ep_chan(EP_PAIR, 2, n0 + wch * WCH * 16, ci, l4); \
+                ep_u2_t q2; q2[0] = 0u; q2[1] = 0u; \
+                if (p.res.p && xnb + xln + bn < p.N && cb < p.Cout) q2 = *(const ep_u2_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
+                ep_xpre[pi][ci / 2] = q2; \
+            } \
+        } \
+    }
+
+// partial statistics of segment sg (EP_SG position blocks of this wave): fixed-order butterfly over the 16 position lanes, one
+// partial per (tile, segment, channel); executed by all lanes
+#define EP_STAT_FLUSH(sg) \
+    if (EP_STAT) { \
+        const int ep_tiles = p.nTW * p.nTH * p.nTD; \
+        const int ep_nblk = ep_tiles * (BM / (EP_SG * 16)); \
+        const int ep_blk = (tile_lin % ep_tiles) * (BM / (EP_SG * 16)) + ep_wpx * (EP_WPX / EP_SG) + (sg); \
+_Pragma("unroll") \
+        for (int ci = 0; ci < WCH; ci += CSTEP) { \
+            const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; ++r) { \
+                float a = ep_sum[EP_STAT ? ci : 0][r], b = ep_sq[EP_STAT ? ci : 0][r]; \
+                ep_sum[EP_STAT ? ci : 0][r] = 0.f; ep_sq[EP_STAT ? ci : 0][r] = 0.f; \
+_Pragma("unroll") \
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); } \
+                if (l15 == 0 && cb < p.Cout) { \
+                    float* dst = p.stat_out + (((long)tn * ep_nblk + ep_blk) * p.Cout + cb + r) * 2; \
+                    dst[0] = a; dst[1] = b; \
+                } \
+            } \
+        } \
+    }
+
 #define CONV_EPILOGUE() \
     constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
     /* per-channel constants of this lane's 4 channels, loaded once (16-byte loads), not once per position block */ \
     float4 ep_bias[WCH], ep_bias2[WCH], ep_s2[WCH], ep_t2[WCH], ep_mean[WCH], ep_rstd[WCH]; \
 _Pragma("unroll") \
     for (int ci = 0; ci < WCH; ci += CSTEP) { \
-        const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
-        const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+        const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
         const bool cok = cb < p.Cout; \
         ep_bias[ci] = (cok && p.bias) ? *(const float4*)(p.bias + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
         ep_bias2[ci] = (cok && MODE == MODE_SPADE) ? *(const float4*)(p.bias2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
@@ -76,6 +186,10 @@ _Pragma("unroll") \
     const float ep_sl0 = lin_slope(p.act0, p.slope0), ep_sl1 = lin_slope(p.act1, p.slope1); \
     constexpr bool EP_STAT = (MODE == MODE_STDSTAT); /* compile-time: the accumulators cost occupancy otherwise */ \
     constexpr int EP_SC = EP_STAT ? WCH : 1; \
+    /* statistics are emitted per 64 positions (4 blocks) also by the waves that own 128: the partial sums - and with them every \
+       bit downstream - do not depend on whether a layer ran as 128x128 or 128x64 tiles (the engine narrows the tiles of launches \
+       that would leave CUs idle) */ \
+    constexpr int EP_SG = EP_WPX > 4 ? 4 : EP_WPX; \
     float ep_sum[EP_SC][4], ep_sq[EP_SC][4]; \
 _Pragma("unroll") \
     for (int ci = 0; ci < EP_SC; ++ci) \
@@ -94,6 +208,10 @@ _Pragma("unroll") \
     constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? 2 : 4))); \
     constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
     const bool ep_fetch = EP_PF && p.res.p != nullptr; \
+    /* channel pairs (EP_PAIR): fp16 tensors whose pointer and strides keep 8 channels 16-byte aligned get one access per pair */ \
+    const bool ep_m0 = EP_PAIR != 0 && !p.out0_f32 && ep_al8(p.out0); \
+    const bool ep_m1 = EP_PAIR != 0 && ep_al8(p.out1); \
+    const bool ep_mr = EP_PAIR != 0 && EP_PF && !p.res_f32 && ep_al8(p.res); \
     const int ep_rshift = (MODE == MODE_SPADE) ? p.res_shift : 0; \
     /* Addressing.  A position of the tile is m = blk * 16 + l15 with blk = ep_wpx * EP_WPX + pi uniform over the wave; the tile's \
        (w, h, d, n) are disjoint bit fields of m, so every coordinate - also after the >> of an up-sampled operand - is the sum of a \
@@ -117,7 +235,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
     for (int pg = 0; pg < EP_WPX; pg += EP_G) { \
     ep_u4_t ep_raw[EP_G][EP_NCI]; float ep_ps[EP_G]; \
-    if (EP_PF && (ep_fetch || p.pixscale)) { \
+    if (EP_PF && !EP_EARLY && (ep_fetch || p.pixscale)) { \
 _Pragma("unroll") \
         for (int g = 0; g < EP_G; ++g) { \
             int bw, bh, bd, bn; \
@@ -129,10 +247,11 @@ _Pragma("unroll") \
                                                             (bw >> ep_rs) * (int)p.res.sW); \
 _Pragma("unroll") \
                 for (int ci = 0; ci < WCH; ci += CSTEP) { \
-                    const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
-                    const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+                    const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
                     if (cb >= p.Cout) continue; \
                     if (p.res_f32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + (xb + (unsigned)cb)); \
+                    else if (ep_mr && ep_second(EP_PAIR, ci)) { /* came with the pair's first half */ } \
+                    else if (ep_mr && cb + 4 < p.Cout) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
                     else { \
                         const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
                         ep_raw[g][(EP_PF ? ci / CSTEP : 0)][0] = q2[0]; ep_raw[g][(EP_PF ? ci / CSTEP : 0)][1] = q2[1]; \
@@ -146,6 +265,7 @@ _Pragma("unroll") \
     for (int g = 0; g < EP_G; ++g) { \
         const int pi = pg + g; \
         if (pi == 1) EP_TL(7); \
+        if (pi > 0 && pi % EP_SG == 0) { EP_STAT_FLUSH(pi / EP_SG - 1) } \
         int bw, bh, bd, bn; \
         { int t = (ep_wpx * EP_WPX + pi) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
         if (ep_nb + ep_ln + bn >= p.N) continue; \
@@ -154,21 +274,27 @@ _Pragma("unroll") \
         const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + (bw >> ep_rs) * (int)p.res.sW); \
         const unsigned ob0 = ep_lane_o0 + (unsigned)(bn * (int)p.out0.sN + bd * (int)p.out0.sD + bh * (int)p.out0.sH + bw * (int)p.out0.sW); \
         const unsigned ob1 = ep_lane_o1 + (unsigned)(bn * (int)p.out1.sN + bd * (int)p.out1.sD + bh * (int)p.out1.sH + bw * (int)p.out1.sW); \
+        float ep_vh[4] = {0.f, 0.f, 0.f, 0.f}, ep_uh[4] = {0.f, 0.f, 0.f, 0.f};      /* first half of a channel pair, held for the joint store */ \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
-            const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
-            const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
+            const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
             if (cb >= p.Cout) continue; \
             float rr[4] = {0.f, 0.f, 0.f, 0.f};     /* residual (STD / TBLEND) or the modulated tensor x (SPADE) */ \
             if (p.res.p) { \
-                if (EP_PF) { \
+                if (EP_EARLY) { \
+                    const h4_t hx = __builtin_bit_cast(h4_t, ep_xpre[EP_EARLY ? pi : 0][EP_EARLY ? ci / 2 : 0]); \
+_Pragma("unroll") \
+                    for (int r = 0; r < 4; ++r) rr[r] = (float)hx[r]; \
+                } else if (EP_PF) { \
+                    const bool ep_hi = ep_mr && ep_second(EP_PAIR, ci);      /* upper half of the pair's 16-byte fetch */ \
                     const ep_u4_t q4 = ep_raw[g][(EP_PF ? ci / CSTEP : 0)]; \
+                    const ep_u4_t qp = ep_raw[g][(EP_PF && ep_second(EP_PAIR, ci) ? ci / CSTEP - 1 : 0)]; \
                     if (p.res_f32) { \
                         const f4_t qf = __builtin_bit_cast(f4_t, q4);     /* whole-vector cast: bit_cast of q4[r] reads element 0 */ \
 _Pragma("unroll") \
                         for (int r = 0; r < 4; ++r) rr[r] = qf[r]; \
                     } else { \
-                        ep_u2_t q2; q2[0] = q4[0]; q2[1] = q4[1]; \
+                        ep_u2_t q2; q2[0] = ep_hi ? qp[2] : q4[0]; q2[1] = ep_hi ? qp[3] : q4[1]; \
                         const h4_t hx = __builtin_bit_cast(h4_t, q2); \
 _Pragma("unroll") \
                         for (int r = 0; r < 4; ++r) rr[r] = (float)hx[r]; \
@@ -214,7 +340,14 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \
-            if (p.out0.p) store4(p.out0, p.out0_f32, (long)(ob0 + (unsigned)cb), v); \
+            const bool ep_hold = EP_PAIR != 0 && !ep_second(EP_PAIR, ci) && cb + 4 < p.Cout;      /* first half of a complete pair */ \
+            if (p.out0.p EP_STORE_COND) { \
+                if (ep_m0 && ep_hold) { \
+_Pragma("unroll") \
+                    for (int r = 0; r < 4; ++r) ep_vh[r] = v[r]; \
+                } else if (ep_m0 && ep_second(EP_PAIR, ci)) store8(p.out0, 0, (long)(ob0 + (unsigned)(cb - 4)), ep_vh, v); \
+                else store4(p.out0, p.out0_f32, (long)(ob0 + (unsigned)cb), v); \
+            } \
             if (EP_STAT) { /* statistics of the values as stored (fp16-rounded when out0 is fp16) */ \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
@@ -229,30 +362,17 @@ _Pragma("unroll") \
                     const float a = v[r] * ((const float*)&ep_s2[ci])[r] + ((const float*)&ep_t2[ci])[r]; \
                     u[r] = lin_act(a, ep_sl1); \
                 } \
-                store4(p.out1, 0, (long)(ob1 + (unsigned)cb), u); \
-            } \
-        } \
-    } \
-    } \
-    if (EP_STAT) { /* fixed-order butterfly over the 16 position lanes, then one partial per (tile, wave, channel) */ \
-        const int ep_tiles = p.nTW * p.nTH * p.nTD; \
-        const int ep_nblk = ep_tiles * (BM / (EP_WPX * 16)); \
-        const int ep_blk = (tile_lin % ep_tiles) * (BM / (EP_WPX * 16)) + ep_wpx; \
+                if (true EP_STORE_COND) { \
+                    if (ep_m1 && ep_hold) { \
 _Pragma("unroll") \
-        for (int ci = 0; ci < WCH; ci += CSTEP) { \
-            const int pb = (n0 + wch * WCH * 16) / 16 + ci; \
-            const int cb = (CSTEP == 2 ? (pb >> 1) : pb) * 16 + l4 * 4; \
-_Pragma("unroll") \
-            for (int r = 0; r < 4; ++r) { \
-                float a = ep_sum[EP_STAT ? ci : 0][r], b = ep_sq[EP_STAT ? ci : 0][r]; \
-_Pragma("unroll") \
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); } \
-                if (l15 == 0 && cb < p.Cout) { \
-                    float* dst = p.stat_out + (((long)tn * ep_nblk + ep_blk) * p.Cout + cb + r) * 2; \
-                    dst[0] = a; dst[1] = b; \
+                        for (int r = 0; r < 4; ++r) ep_uh[r] = u[r]; \
+                    } else if (ep_m1 && ep_second(EP_PAIR, ci)) store8(p.out1, 0, (long)(ob1 + (unsigned)(cb - 4)), ep_uh, u); \
+                    else store4(p.out1, 0, (long)(ob1 + (unsigned)cb), u); \
                 } \
             } \
         } \
-    }
+    } \
+    } \
+    EP_STAT_FLUSH((EP_WPX - 1) / EP_SG)
 
 

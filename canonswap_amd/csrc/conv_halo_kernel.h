@@ -103,6 +103,11 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wpx = SK ? 0 : wave % WVP, wch = SK ? 0 : wave / WVP;
     const int l15 = lane & 15, l4 = lane >> 4;
+#ifdef CS_NO_PAIR                               // A/B builds (tools/build_variant.py)
+    constexpr int EP_PAIR = 0;
+#else
+    constexpr int EP_PAIR = ep_pair_of(MODE, WCH);     // weight-row permutation / joint stores of channel pairs (conv_epilogue.h)
+#endif
 
     // position tile / channel block of this workgroup (ConvParams::xcd_map)
     int tile_lin = blockIdx.x, cblk = blockIdx.y;
@@ -216,8 +221,20 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // weights: fragment ci of K-step kidx = 1 KiB at wgt + (kidx*Cout_pad + n0 + wch*WCH*16 + ci*16)*32; lane = (row l15, k l4*8)
     const half_t* wbase = p.wgt;
     if (p.wslot) wbase += p.wofs[p.wslot[nb < p.N ? nb : p.N - 1]];         // per-sample weight set (uniform over the tile)
-    const half_t* wlane = wbase + ((long)(n0 + wch * WCH * 16) * 32 + l15 * 32 + l4 * 8);
+    // EP_PAIR (conv_epilogue.h): the rows of a fragment pair are permuted so that a lane ends up with 8 consecutive output channels
+    const half_t* wlane = wbase + ((long)(n0 + wch * WCH * 16) * 32 + ep_lane_row(EP_PAIR, l15) * 32 + l4 * 8);
     const long wstep = (long)p.Cout_pad * 32;
+
+    // SPADE: fetch the modulated tensor of the whole tile now (conv_epilogue.h); only the 3-waves-per-SIMD 128x128 kernel has the
+    // 16 registers to spare, and launch_halo_st refuses an fp32 operand for it
+#ifdef CS_NO_EARLY
+    constexpr bool EP_EARLY = false;
+#else
+    constexpr bool EP_EARLY = (MODE == MODE_SPADE) && !SK && ST != 0 && WCH == 2 && WPX == 8;
+#endif
+    constexpr int EP_WPX0 = WPX;
+    const int ep_wpx0 = wpx;
+    CONV_EPILOGUE_EARLY_FETCH()
 
     f4_t acc[WCH][WPX];
 #pragma unroll
@@ -237,7 +254,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             const int ccl = cc < nck ? cc : nck - 1;
             const half_t* src = wlane + (long)((ccl * KH32 + st % KH32) * NT + st / KH32) * wstep;
 #pragma unroll
-            for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const u4_t*)(src + ci * 512);
+            for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const u4_t*)(src + ep_frag_row(EP_PAIR, ci) * 32);
         };
         TL_STAMP(1);
         stage_halo(0, cc_lo * CK);
@@ -330,10 +347,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             // counted wait below is exact in steady state and conservative otherwise
             const half_t* src = wlane + last_off;
             wfrag_load<0>(dst[0], src);
-            if constexpr (WCH > 1) wfrag_load<1024>(dst[1], src);
-            if constexpr (WCH > 2) wfrag_load<2048>(dst[2], src);
-            if constexpr (WCH > 3) wfrag_load<3072>(dst[3], src);
-            if constexpr (WCH > 4) wfrag_load<0>(dst[4], src + 2048);
+            if constexpr (WCH > 1) wfrag_load<ep_frag_row(EP_PAIR, 1) * 64>(dst[1], src);
+            if constexpr (WCH > 2) wfrag_load<ep_frag_row(EP_PAIR, 2) * 64>(dst[2], src);
+            if constexpr (WCH > 3) wfrag_load<ep_frag_row(EP_PAIR, 3) * 64>(dst[3], src);
+            if constexpr (WCH > 4) wfrag_load<0>(dst[4], src + ep_frag_row(EP_PAIR, 4) * 32);
         };
 
         u4_t wr[PFD][WCH];
@@ -402,7 +419,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr bool EP_HEAVY = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
     TL_STAMP(3);
     if constexpr (!SK) {
-        if (p.sk_out) {      // split-K: this workgroup's partial sums, fp32, [split][position][packed channel]; finished by splitk_finish_kernel
+        if (p.sk_out) {      // split-K: this workgroup's partial sums, fp32, [split][position][channel]; finished by splitk_finish_kernel
             const long mtot = (long)p.N * p.D * p.H * p.W;
 #pragma unroll
             for (int pi = 0; pi < WPX; ++pi) {
@@ -415,7 +432,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 const long pos = (((long)n * p.D + d) * p.H + h) * p.W + w;
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
-                    *(f4_t*)(p.sk_out + ((long)blockIdx.z * mtot + pos) * p.Cout_pad + n0 + wch * WCH * 16 + ci * 16 + l4 * 4) = acc[ci][pi];
+                    *(f4_t*)(p.sk_out + ((long)blockIdx.z * mtot + pos) * p.Cout_pad + ep_chan(EP_PAIR, 1, n0 + wch * WCH * 16, ci, l4)) = acc[ci][pi];
             }
         } else {
         constexpr int EP_WPX = WPX;
@@ -500,6 +517,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     const int lgS = p.lgTW + p.lgTH + p.lgTD;
     if ((1 << lgS) > BM) { cs_set_error("conv_halo: spatial tile exceeds BM"); return -1; }
     if (MODE == MODE_SPADE && (1 << lgS) != BM) { cs_set_error("conv_halo: SPADE launches must tile within one sample"); return -1; }
+    if (MODE == MODE_SPADE && p.res_f32) { cs_set_error("conv_halo: the tensor a SPADE launch modulates is fp16"); return -1; }
     if (p.wslot && (1 << lgS) != BM) { cs_set_error("conv_halo: per-sample weight sets need tiles within one sample"); return -1; }
     const int TN = BM >> lgS;
     const long HV = (long)TN * ((1 << p.lgTD) + p.KD - 1) * ((1 << p.lgTH) + p.KH - 1) * ((1 << p.lgTW) + p.KW - 1);

@@ -278,7 +278,15 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     // (below 3 frames a 128x256 launch is 128 workgroups or fewer: 128x128 tiles put one on every CU; same K order, same bits)
     if (mode == MODE_TBLEND && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0 &&
         (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
-    if (Cout_pad % 128 == 0) return CFG_H_128x128;
+    if (Cout_pad % 128 == 0) {
+        // a launch of 128 or fewer 128x128 workgroups leaves half of the 256 CUs idle (one frame: the 512-channel 3x3 convs at 64x64
+        // are 32 x 4): 128x64 tiles put a workgroup on every CU.  Same K order per output element, same bits.
+        static const bool narrow = [] { const char* s = getenv("CANONSWAP_NARROW"); return !s || atoi(s) != 0; }();
+        const long tiles = ((long)p.N * p.D * p.H * p.W + 127) / 128;
+        if (narrow && (mode == MODE_STD || mode == MODE_STDSTAT) && p.KH == 3 && p.KW == 3 && tiles * (Cout_pad / 128) <= 128)
+            return CFG_H_128x64;
+        return CFG_H_128x128;
+    }
     if (Cout_pad % 64 == 0) return CFG_H_128x64;
     if (Cout_pad % 32 == 0) return CFG_H_128x32;
     return CFG_H_128x16;
@@ -301,8 +309,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         if (!prefW) { prefW = is3d ? 8 : 16; prefH = is3d ? 8 : BM / 16; }
         set_tile(c.p, BM, prefW, prefH);
         {   // positions covered by one wave in the epilogue -> partial-statistics blocks per sample
-            int wave_px = 128;
-            if (hcfg == CFG_H_128x64 || hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_128x160) wave_px = 64;
+            int wave_px = 64;      // waves that own 128 positions emit two partials (conv_epilogue.h, EP_SG)
             if (hcfg == CFG_H_128x32 || hcfg == CFG_H_128x16 || hcfg == CFG_H_SK128x32) wave_px = 32;
             c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (BM / wave_px);
         }
@@ -321,8 +328,10 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
             const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
                                c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0;
-            if (sk_on && plain && wgs <= 96 && nck >= 4 && e->sk_buf) {
-                int splits = (int)(256 / wgs);
+            static const int sk_maxwg = [] { const char* s = getenv("CANONSWAP_SK_MAXWG"); return s ? atoi(s) : 64; }();   // r02 sweep
+            static const int sk_fill = [] { const char* s = getenv("CANONSWAP_SK_FILL"); return s ? atoi(s) : 512; }();
+            if (sk_on && plain && wgs <= sk_maxwg && nck >= 4 && e->sk_buf) {
+                int splits = (int)(sk_fill / wgs);
                 if (splits > nck) splits = nck;
                 if (splits > 16) splits = 16;
                 while (splits > 1 && (size_t)splits * mtot * c.p.Cout_pad > e->sk_cap) --splits;

@@ -36,9 +36,27 @@ void run(const ConvParams& p, int BM)
         const int mW = (1 << p.lgTW) - 1, mH = (1 << p.lgTH) - 1, mD = (1 << p.lgTD) - 1;
         const int wpx = wave % WVP, wch = wave / WVP;
         const int l15 = lane & 15, l4 = lane >> 4;
+#ifdef HARNESS_NO_PAIRING
+        constexpr int EP_PAIR = 0;
+#else
+        constexpr int EP_PAIR = ep_pair_of(MODE, WCH);
+#endif
+        // the accumulators as the kernel's MFMAs would leave them: a function of (packed weight row, position) only, so the
+        // checksums do not depend on which lane / fragment a row is assigned to (EP_PAIR)
         f4_t acc[WCH][WPX];
-        for (int ci = 0; ci < WCH; ++ci) for (int pi = 0; pi < WPX; ++pi) for (int r = 0; r < 4; ++r)
-            acc[ci][pi][r] = rnd(((tile * 4 + wave) * 64 + lane) * 97 + (ci * WPX + pi) * 4 + r + cb * 7919);
+        for (int ci = 0; ci < WCH; ++ci) for (int pi = 0; pi < WPX; ++pi) for (int r = 0; r < 4; ++r) {
+            const int row = n0 + wch * WCH * 16 + ep_frag_row(EP_PAIR, ci) + ep_lane_row(EP_PAIR, l4 * 4 + r);
+            const int m = (wpx * WPX + pi) * 16 + l15;
+            acc[ci][pi][r] = rnd((uint32_t)((tile * 1024 + m) * 2053 + row * 31 + 7));
+        }
+#ifdef HARNESS_NO_PAIRING
+        constexpr bool EP_EARLY = false;
+#else
+        constexpr bool EP_EARLY = (MODE == MODE_SPADE) && WCH == 2 && WPX == 8;      // as conv_halo_kernel.h
+#endif
+        constexpr int EP_WPX0 = WPX;
+        const int ep_wpx0 = wpx;
+        CONV_EPILOGUE_EARLY_FETCH()
         constexpr int EP_WPX = WPX;
         const int ep_wpx = wpx;
         auto& ep_acc = acc;
@@ -137,6 +155,51 @@ int main()
         q.out0 = TDesc{o.data(), (long)q.D * q.H * q.W * 160, (long)q.H * q.W * 160, (long)q.W * 160, 160}; q.out0_f32 = 1; q.ps_stride = 1;
         run<4, 5, 2, 2, MODE_STD, false>(q, 128);
         printf("case6b %016llx\n", (unsigned long long)crc(o.data(), o.size() * 4));
+    }
+    // case 7: channel count that ends in the middle of a lane's 8-channel pair (196 = 24 * 8 + 4), fp16 residual, both outputs fp16;
+    // 7b: the same with an fp32 first output and the T-blend kernel shape on 100 of 128 output channels (2 x 128 packed rows)
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 1; p.H = 8; p.W = 32; p.Cout = 196; p.Cout_pad = 256; tile_of(p, 128, 16, 8);
+        const size_t P = (size_t)p.N * p.H * p.W;
+        auto res = H(P * 200, 61); auto bias = F(256, 62), s2 = F(256, 63), t2 = F(256, 64);
+        std::vector<half_t> out0(P * 200, (half_t)-9.f), out1(P * 196, (half_t)-9.f);
+        p.res = TDesc{res.data(), (long)p.H * p.W * 200, 0, (long)p.W * 200, 200}; p.res_f32 = 0;
+        p.out0 = TDesc{out0.data(), (long)p.H * p.W * 200, 0, (long)p.W * 200, 200};
+        p.out1 = TDesc{out1.data(), (long)p.H * p.W * 196, 0, (long)p.W * 196, 196};
+        p.bias = bias.data(); p.s2 = s2.data(); p.t2 = t2.data(); p.act0 = ACT_LRELU; p.slope0 = 0.1f; p.act1 = ACT_RELU; p.ps_stride = 1;
+        run<8, 2, 1, 4, MODE_STD, false>(p, 128);
+        printf("case7 %016llx %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 2), (unsigned long long)crc(out1.data(), out1.size() * 2));
+        ConvParams q; memset(&q, 0, sizeof q);
+        q.N = 1; q.D = 1; q.H = 16; q.W = 16; q.Cout = 100; q.Cout_pad = 256; tile_of(q, 128, 16, 8);
+        const size_t Q = (size_t)q.N * q.H * q.W;
+        auto r2 = F(Q * 100, 71), ps = F(Q, 72), b2 = F(128, 73);
+        std::vector<float> o0(Q * 100, -9.f); std::vector<half_t> o1(Q * 100, (half_t)-9.f);
+        q.res = TDesc{r2.data(), (long)q.H * q.W * 100, 0, (long)q.W * 100, 100}; q.res_f32 = 1;
+        q.out0 = TDesc{o0.data(), (long)q.H * q.W * 100, 0, (long)q.W * 100, 100}; q.out0_f32 = 1;
+        q.out1 = TDesc{o1.data(), (long)q.H * q.W * 100, 0, (long)q.W * 100, 100};
+        q.bias = b2.data(); q.pixscale = ps.data(); q.ps_stride = 1; q.act1 = ACT_RELU;
+        run<8, 4, 1, 4, MODE_TBLEND, false>(q, 128);
+        printf("case7b %016llx %016llx\n", (unsigned long long)crc(o0.data(), o0.size() * 4), (unsigned long long)crc(o1.data(), o1.size() * 2));
+    }
+    // case 8: statistics are emitted per 64 positions: the 128x128 kernel shape (a wave owns 128 positions) and the 128x64 shape
+    // (64 per wave) must leave the same partial sums and the same output
+    {
+        uint64_t c0[2], c1[2];
+        for (int v = 0; v < 2; ++v) {
+            ConvParams p; memset(&p, 0, sizeof p);
+            p.N = 2; p.D = 1; p.H = 16; p.W = 32; p.Cout = 120; p.Cout_pad = 128; tile_of(p, 128, 16, 8);
+            const size_t P = (size_t)p.N * p.H * p.W;
+            auto bias = F(128, 81); auto res = H(P * 120, 82);
+            std::vector<half_t> out0(P * 120, (half_t)-9.f);
+            std::vector<float> st((size_t)p.N * (p.H * p.W / 64) * 120 * 2, -9.f);
+            p.res = TDesc{res.data(), (long)p.H * p.W * 120, 0, (long)p.W * 120, 120};
+            p.out0 = TDesc{out0.data(), (long)p.H * p.W * 120, 0, (long)p.W * 120, 120};
+            p.bias = bias.data(); p.act0 = ACT_RELU; p.ps_stride = 1; p.stat_out = st.data();
+            if (v == 0) run<8, 2, 1, 4, MODE_STDSTAT, false>(p, 128); else run<4, 2, 2, 2, MODE_STDSTAT, false>(p, 128);
+            c0[v] = crc(out0.data(), out0.size() * 2); c1[v] = crc(st.data(), st.size() * 4);
+        }
+        printf("case8 %016llx %016llx same=%d\n", (unsigned long long)c0[0], (unsigned long long)c1[0], (int)(c0[0] == c0[1] && c1[0] == c1[1]));
     }
     return 0;
 }

@@ -22,8 +22,12 @@ def test_epilogue_macro_on_host(tmp_path):
     (tmp_path / "common_stub.h").write_text(common[: common.index("#define CS_CHECK_HIP")])
     (tmp_path / "ep.h").write_text(open(os.path.join(csrc, "conv_epilogue.h")).read().replace('#include "common.h"', ""))
     shutil.copy(os.path.join(HERE, "harness.cpp"), tmp_path / "h.cpp")
-    exe = str(tmp_path / "h")
-    subprocess.run([CLANG, "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-everything", '-DEPH="ep.h"', "h.cpp", "-o", exe],
-                   cwd=tmp_path, check=True)
-    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
-    assert out == open(os.path.join(HERE, "expected.txt")).read()
+    # The harness fills the accumulators as a function of (packed weight row, position), so the kernels' channel pairing (EP_PAIR:
+    # which lane / fragment a weight row goes to, joint 16-byte stores of a lane's 8 channels) must give the same bytes as the
+    # plain mapping: both variants are compared with the same expected checksums.
+    for flags in (["-DHARNESS_NO_PAIRING"], []):
+        exe = str(tmp_path / ("h" + str(len(flags))))
+        subprocess.run([CLANG, "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-everything", '-DEPH="ep.h"', *flags, "h.cpp", "-o", exe],
+                       cwd=tmp_path, check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout
+        assert out == open(os.path.join(HERE, "expected.txt")).read(), flags
