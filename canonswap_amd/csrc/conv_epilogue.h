@@ -10,6 +10,27 @@
 typedef unsigned int ep_u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int ep_u2_t __attribute__((ext_vector_type(2)));
 
+// Host side: the epilogue addresses its tensors with 32-bit element offsets and 24-bit per-axis multiplies; both conv launchers
+// call this before launching.
+static inline int ep_check_extents(const ConvParams& p, const char* who)
+{
+    auto span = [&](const TDesc& t) -> long {
+        return (long)(p.N - 1) * t.sN + (long)(p.D - 1) * t.sD + (long)(p.H - 1) * t.sH + (long)(p.W - 1) * t.sW + p.Cout;
+    };
+    auto wide = [&](const TDesc& t) { return t.sD >= (1L << 23) || t.sH >= (1L << 23) || t.sW >= (1L << 23); };
+    const long lim = 1L << 31;
+    if ((p.out0.p && span(p.out0) >= lim) || (p.out1.p && span(p.out1) >= lim) || (p.res.p && span(p.res) >= lim)) {
+        cs_set_error("%s: a tensor of this launch spans 2^31 elements or more (32-bit in-tensor offsets)", who);
+        return -1;
+    }
+    if ((p.out0.p && wide(p.out0)) || (p.out1.p && wide(p.out1)) || (p.res.p && wide(p.res)) || p.D >= (1 << 22) || p.H >= (1 << 22) ||
+        p.W >= (1 << 22)) {
+        cs_set_error("%s: an axis stride of 2^23 elements or more (24-bit multiplies in the addressing)", who);
+        return -1;
+    }
+    return 0;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -124,8 +145,8 @@ __device__ __forceinline__ constexpr int ep_pair_of(int mode, int wch)
         int xlw, xlh, xld, xln; \
         { int t = l15; xlw = t & mW; t >>= lgTW; xlh = t & mH; t >>= lgTH; xld = t & mD; t >>= lgTD; xln = t; } \
         const int xrs = p.res_shift, xnb = tn * (BM >> lgS); \
-        const unsigned xlane = (unsigned)((xnb + xln) * (int)p.res.sN + ((td << lgTD) + xld) * (int)p.res.sD + \
-                                          (((th << lgTH) + xlh) >> xrs) * (int)p.res.sH + (((tw << lgTW) + xlw) >> xrs) * (int)p.res.sW); \
+        const unsigned xlane = (unsigned)((xnb + xln) * (int)p.res.sN + __mul24((td << lgTD) + xld, (int)p.res.sD) + \
+                                          __mul24(((th << lgTH) + xlh) >> xrs, (int)p.res.sH) + __mul24(((tw << lgTW) + xlw) >> xrs, (int)p.res.sW)); \
 _Pragma("unroll") \
         for (int pi = 0; pi < EP_WPX0; ++pi) { \
             int bw, bh, bd, bn; \
@@ -223,12 +244,15 @@ _Pragma("unroll") \
     { int t = l15; ep_lw = t & mW; t >>= lgTW; ep_lh = t & mH; t >>= lgTH; ep_ld = t & mD; t >>= lgTD; ep_ln = t; } \
     const int ep_w0 = tw << lgTW, ep_h0 = th << lgTH, ep_d0 = td << lgTD, ep_nb = tn * (BM >> lgS); \
     const int ep_rs = (MODE == MODE_SPADE) ? p.res_shift : 0; \
-    const unsigned ep_lane_res = (unsigned)((ep_nb + ep_ln) * (int)p.res.sN + (ep_d0 + ep_ld) * (int)p.res.sD + \
-                                            ((ep_h0 + ep_lh) >> ep_rs) * (int)p.res.sH + ((ep_w0 + ep_lw) >> ep_rs) * (int)p.res.sW); \
-    const unsigned ep_lane_o0 = (unsigned)((ep_nb + ep_ln) * (int)p.out0.sN + (ep_d0 + ep_ld) * (int)p.out0.sD + \
-                                           (ep_h0 + ep_lh) * (int)p.out0.sH + (ep_w0 + ep_lw) * (int)p.out0.sW); \
-    const unsigned ep_lane_o1 = (unsigned)((ep_nb + ep_ln) * (int)p.out1.sN + (ep_d0 + ep_ld) * (int)p.out1.sD + \
-                                           (ep_h0 + ep_lh) * (int)p.out1.sH + (ep_w0 + ep_lw) * (int)p.out1.sW); \
+    /* per-axis products as 24-bit multiplies (full rate; coordinates are small, launchers refuse axis strides >= 2^23); the \
+       sample term only where a tile spans several samples */ \
+    const bool ep_tn1 = (BM >> lgS) == 1; \
+    const unsigned ep_lane_res = (unsigned)(ep_nb * (int)p.res.sN + (ep_tn1 ? 0 : ep_ln * (int)p.res.sN) + __mul24(ep_d0 + ep_ld, (int)p.res.sD) + \
+                                            __mul24((ep_h0 + ep_lh) >> ep_rs, (int)p.res.sH) + __mul24((ep_w0 + ep_lw) >> ep_rs, (int)p.res.sW)); \
+    const unsigned ep_lane_o0 = (unsigned)(ep_nb * (int)p.out0.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out0.sN) + __mul24(ep_d0 + ep_ld, (int)p.out0.sD) + \
+                                           __mul24(ep_h0 + ep_lh, (int)p.out0.sH) + __mul24(ep_w0 + ep_lw, (int)p.out0.sW)); \
+    const unsigned ep_lane_o1 = (unsigned)(ep_nb * (int)p.out1.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out1.sN) + __mul24(ep_d0 + ep_ld, (int)p.out1.sD) + \
+                                           __mul24(ep_h0 + ep_lh, (int)p.out1.sH) + __mul24(ep_w0 + ep_lw, (int)p.out1.sW)); \
     const unsigned ep_lane_ps = (unsigned)(((((ep_nb + ep_ln) * p.D + ep_d0 + ep_ld) * p.H + ep_h0 + ep_lh) * p.W + ep_w0 + ep_lw) * p.ps_stride); \
     /* pixel shuffle: out[n][c][2h + i][2w + j], H2 = 2H, W2 = 2W */ \
     const unsigned ep_lane_px = (unsigned)((((ep_nb + ep_ln) * 3) * 2 * p.H + 2 * (ep_h0 + ep_lh)) * 2 * p.W + 2 * (ep_w0 + ep_lw)); \
@@ -332,11 +356,13 @@ _Pragma("unroll") \
                 } \
                 continue; \
             } \
-            if (MODE != MODE_SPADE && p.res.p) { \
+            /* no residual: rr == 0; no per-position scale: ps == 1 - applied unconditionally (a select per element costs more issue \
+               slots than the add / multiply it would skip; the epilogue is VALU-issue-bound, profiles/r02_store_ablation.txt) */ \
+            if (MODE != MODE_SPADE) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
             } \
-            if ((MODE == MODE_STD || MODE == MODE_STDSTAT) && p.pixscale) { \
+            if (MODE == MODE_STD || MODE == MODE_STDSTAT) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \

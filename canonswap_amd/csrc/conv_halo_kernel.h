@@ -141,16 +141,20 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // ---- halo staging, global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).
     // The LDS image is linear in the piece index q = voxel*SLP + slot (SLP = SL data slots + 1 pad slot), which is
     // what the instruction requires (wave-uniform base + lane*16). Out-of-range / pad pieces read the zero page.
-    auto piece_off = [&](int q, bool& inb) -> long {      // element offset of piece q's voxel (without the channel part)
+    // 32-bit offsets; the per-axis products are 24-bit multiplies (full rate; v_mul_lo_u32 / the 64-bit forms are quarter rate and
+    // this runs 13 times per thread in the volume kernels): coordinates are small and launch_halo_st refuses axis strides >= 2^23
+    const int isN = (int)p.in_sN, isD = (int)p.in_sD, isH = (int)p.in_sH, isW = (int)p.in_sW;
+    const int in_nb = nb * isN;                                                   // scalar
+    auto piece_off = [&](int q, bool& inb) -> int {       // element offset of piece q's voxel (without the channel part)
         const int hv = q / SLP;
         const int hw = hv % HW; int r = hv / HW;
         const int hh = r % HH; r /= HH;
         const int hd = r % HD;
-        const int hn = r / HD;
+        const int hn = TN == 1 ? 0 : r / HD;
         const int n = nb + hn, id = d0 + hd - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW;
-        inb = q < nitems && (q % SLP) < SL && n < p.N && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H &&
-              (unsigned)iw < (unsigned)p.W;
-        return (long)n * p.in_sN + (long)id * p.in_sD + (long)(ih >> p.up_shift) * p.in_sH + (long)(iw >> p.up_shift) * p.in_sW +
+        inb = q < nitems && (q % SLP) < SL && (TN == 1 ? r < HD : true) && n < p.N && (unsigned)id < (unsigned)p.D &&
+              (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        return in_nb + (TN == 1 ? 0 : hn * isN) + __mul24(id, isD) + __mul24(ih >> p.up_shift, isH) + __mul24(iw >> p.up_shift, isW) +
                (q % SLP) * 8;
     };
     // few pieces per thread: keep their offsets in registers (always the case in double-buffered mode, see launcher)
@@ -161,8 +165,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #pragma unroll
         for (int j = 0; j < HI; ++j) {
             bool inb;
-            const long o = piece_off(tid + 256 * j, inb);
-            poff[j] = inb ? (int)o : 0;
+            const int o = piece_off(tid + 256 * j, inb);
+            poff[j] = inb ? o : 0;
             pmask |= inb ? (1u << j) : 0u;
         }
     }
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 const int q = q0 + tid;
                 if (q < nitems) {
                     bool inb;
-                    const long o = piece_off(q, inb);
+                    const int o = piece_off(q, inb);
                     const bool ok = inb && ((q % SLP) * 8 < climit);
                     glds(ok ? p.in + o + coff : p.zero, buf, q0 + wave * 64);
                 }
@@ -495,18 +499,16 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP, BN = WCH * 16 * WVC;
     constexpr int SLP = CK / 8 + 1, VS = SLP * 16;
     if (p.Cout_pad % BN != 0) { cs_set_error("conv_halo: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
-    {   // in-tensor element offsets are kept in 32 bits inside the kernel (halo piece offsets, epilogue addressing)
-        auto extent = [&](long sN, long sD, long sH, long sW, int C) -> long {
-            return (long)(p.N - 1) * sN + (long)(p.D - 1) * sD + (long)(p.H - 1) * sH + (long)(p.W - 1) * sW + C;
-        };
-        const long lim = 1L << 31;
-        if (extent(p.in_sN, p.in_sD, p.in_sH >> 0, p.in_sW, p.Cin) + (p.cg > 0 ? (long)(p.nchunks / p.cg) * p.in_sG : 0) >= lim ||
-            (p.out0.p && extent(p.out0.sN, p.out0.sD, p.out0.sH, p.out0.sW, p.Cout) >= lim) ||
-            (p.out1.p && extent(p.out1.sN, p.out1.sD, p.out1.sH, p.out1.sW, p.Cout) >= lim) ||
-            (p.res.p && extent(p.res.sN, p.res.sD, p.res.sH, p.res.sW, p.Cout) >= lim)) {
-            cs_set_error("conv_halo: a tensor of this launch spans 2^31 elements or more (32-bit in-tensor offsets)");
+    {   // in-tensor element offsets are kept in 32 bits inside the kernel, per-axis products in 24 (halo piece offsets; the epilogue's
+        // tensors: ep_check_extents)
+        const long in_span = (long)(p.N - 1) * p.in_sN + (long)(p.D - 1) * p.in_sD + (long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW +
+                             p.Cin + (p.cg > 0 ? (long)(p.nchunks / p.cg) * p.in_sG : 0);
+        if (in_span >= (1L << 31)) { cs_set_error("conv_halo: the input spans 2^31 elements or more (32-bit in-tensor offsets)"); return -1; }
+        if (p.in_sD >= (1L << 23) || p.in_sH >= (1L << 23) || p.in_sW >= (1L << 23)) {
+            cs_set_error("conv_halo: an input axis stride of 2^23 elements or more (24-bit multiplies in the addressing)");
             return -1;
         }
+        if (ep_check_extents(p, "conv_halo")) return -1;
     }
     constexpr bool heavy_ok = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
     if ((!heavy_ok && p.act0 >= ACT_SIGMOID) || p.act1 >= ACT_SIGMOID) {

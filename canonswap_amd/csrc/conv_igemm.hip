@@ -171,6 +171,7 @@ int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st)
 {
     if (p.wslot) { cs_set_error("conv_igemm: per-sample weight sets are only implemented by conv_halo"); return -1; }
     if (p.act1 >= ACT_SIGMOID) { cs_set_error("conv_igemm: the second output takes none / ReLU / LeakyReLU only"); return -1; }
+    if (ep_check_extents(p, "conv_igemm")) return -1;
     if (mode == MODE_STD && p.stat_out) {
         switch (cfg) {
         case CFG_128x128: return launch_cfg<4, 4, 2, 2, MODE_STDSTAT>(p, st);

@@ -11,6 +11,8 @@ static inline float4 make_float4(float a, float b, float c, float d) { return {a
 static inline float2 make_float2(float a, float b) { return {a, b}; }
 #define __expf expf
 static inline float __shfl_xor(float a, int, int) { return a; }
+static inline int __mul24(int a, int b) { return (int)(((long long)(a << 8 >> 8)) * (b << 8 >> 8)); }      // v_mul_i32_i24: low 24 bits of each
+static void cs_set_error(const char*, ...) {}
 #define hipStream_t void*
 #include "common_stub.h"
 #include EPH
