@@ -83,6 +83,8 @@ struct ConvParams {
     // split order (deterministic) and applies bias / activation / output conversion.  nullptr: off.
     float* sk_out;
     int sk_splits;
+    // conv_halo: multiply-high constants for workgroup index / {channel blocks, nTW, nTH, nTD} (set by the launcher; 0: divisor 1)
+    unsigned mg_ncb, mg_tw, mg_th, mg_td;
     // split-precision convs (activations [hi | lo], weights [W_hi | W_lo | W_hi] in three 32-channel chunks): weight chunks 0 and 1 both
     // multiply the activation chunk 0 (hi), chunk 2 multiplies activation chunk 1 (lo) - the hi halo is staged once.  0: off.
     int hilo;

@@ -27,6 +27,8 @@
 // explicit counted s_waitcnt: hipcc drains vmcnt to 0 at every loop back-edge for loads it tracks, which would
 // collapse the PFD-deep register ring to an effective depth of one K-step.
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned mdiv(unsigned u, unsigned magic) { return magic ? __umulhi(u, magic) : u; }
+
 template <int OFF>
 __device__ __forceinline__ void wfrag_load(u4_t& dst, const half_t* ptr)
 {
@@ -118,13 +120,14 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
         const int q = total >> 3, r = total & 7;
         const int u = xcd * q + (xcd < r ? xcd : r) + i;                // bijection: XCD x owns q + (x < r) consecutive entries
-        if (flat) { tile_lin = u / ncb; cblk = u - tile_lin * ncb; }
+        if (flat) { tile_lin = (int)mdiv((unsigned)u, p.mg_ncb); cblk = u - tile_lin * ncb; }
         else tile_lin = u;
     }
-    int t = tile_lin;
-    const int tw = t % p.nTW; t /= p.nTW;
-    const int th = t % p.nTH; t /= p.nTH;
-    const int td = t % p.nTD; t /= p.nTD;
+    // (mg_*: multiply-high constants of launch_halo_st for these divisions)
+    int t = tile_lin, tq;
+    tq = (int)mdiv((unsigned)t, p.mg_tw); const int tw = t - tq * p.nTW; t = tq;
+    tq = (int)mdiv((unsigned)t, p.mg_th); const int th = t - tq * p.nTH; t = tq;
+    tq = (int)mdiv((unsigned)t, p.mg_td); const int td = t - tq * p.nTD; t = tq;
     const int tn = t;
     const int n0 = cblk * BN;
     const int lgTW = ST ? SS::LW : p.lgTW, lgTH = ST ? SS::LH : p.lgTH, lgTD = ST ? SS::LD : p.lgTD;
@@ -545,6 +548,17 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1);
     hipError_t e;
     ConvParams kp = p;
+    {   // exact division of the workgroup index by the tile counts as one multiply-high each (u / d == umulhi(u, 2^32 / d + 1) while
+        // u * d < 2^32; 0 encodes d == 1): four runtime integer divisions cost every workgroup about a hundred issue slots
+        const unsigned long long umax = (unsigned long long)grid.x * grid.y;
+        const unsigned ds[4] = {(unsigned)(p.Cout_pad / BN), (unsigned)p.nTW, (unsigned)p.nTH, (unsigned)p.nTD};
+        unsigned mg[4];
+        for (int i = 0; i < 4; ++i) {
+            if (ds[i] == 0 || umax * ds[i] >= (1ull << 32)) { cs_set_error("conv_halo: launch of %llu workgroups / tile count %u too large", umax, ds[i]); return -1; }
+            mg[i] = ds[i] == 1 ? 0u : (unsigned)((1ull << 32) / ds[i]) + 1u;
+        }
+        kp.mg_ncb = mg[0]; kp.mg_tw = mg[1]; kp.mg_th = mg[2]; kp.mg_td = mg[3];
+    }
 #ifdef CS_TIMELINE
     kp.tl = g_cs_tl; kp.tl_cap = g_cs_tl_cap;
 #endif
