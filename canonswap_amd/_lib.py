@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_unpack_u8", "cs_soft_erosion", "cs_prepare_crops", "cs_warp_affine_u8", "cs_warp_affine_f32", "cs_paste_back",
     "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
-    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats",
+    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -100,7 +100,7 @@ class ConvDesc(C.Structure):
         ("s2", C.c_void_p), ("t2", C.c_void_p), ("act1", C.c_int), ("slope1", C.c_float),
         ("out1", C.c_void_p), ("out1_sN", C.c_long), ("out1_sD", C.c_long), ("out1_sH", C.c_long), ("out1_sW", C.c_long),
         ("stats", C.c_void_p),
-        ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int), ("xcd_map", C.c_int),
+        ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int), ("xcd_map", C.c_int), ("ragged", C.c_int),
     ]
 
 
@@ -153,6 +153,7 @@ def load():
     lib.cs_op_conv.argtypes = [C.POINTER(ConvDesc), vp]
     lib.cs_op_grid_sample3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.cs_op_chan_stats.argtypes = [vp, ci, ci, C.c_long, ci, cf, vp, vp, vp]
+    lib.cs_op_pair_ragged.argtypes = [vp, ci, ci, ci, ci, ci, vp]
     lib.cs_op_chan_stats_partial_floats.argtypes = [ci, C.c_long, ci]
     lib.cs_op_chan_stats_partial_floats.restype = C.c_long
     _lib = lib

@@ -83,6 +83,9 @@ struct ConvParams {
     // split order (deterministic) and applies bias / activation / output conversion.  nullptr: off.
     float* sk_out;
     int sk_splits;
+    // conv_halo, Cin % 32 == 16: the last 32-channel chunk holds 16 real channels; its weight rows were re-packed by
+    // launch_pair_ragged so that two taps that are neighbours along the row share one 32-deep K-step (conv_halo_kernel.h, RAG)
+    int ragged;
     // conv_halo: multiply-high constants for workgroup index / {channel blocks, nTW, nTH, nTD} (set by the launcher; 0: divisor 1)
     unsigned mg_ncb, mg_tw, mg_th, mg_td;
     // split-precision convs (activations [hi | lo], weights [W_hi | W_lo | W_hi] in three 32-channel chunks): weight chunks 0 and 1 both
@@ -133,6 +136,8 @@ int launch_norm_act(const float* y, const float* stats, const float* gamma, cons
                     int act2, float slope2, int N, long per_n, hipStream_t st, int split = 0);
 int launch_split16(const float* x, half_t* out, long n, hipStream_t st);
 int launch_splitk_finish(const ConvParams& p, hipStream_t st);
+// re-pack the last chunk of a packed conv weight [chunk * taps][Cout_pad][32] for ConvParams::ragged (in place, via a scratch copy)
+int launch_pair_ragged(half_t* w, int Cout_pad, int nchunks, int KD, int KH, int KW, hipStream_t st);
 int launch_absmax16(const half_t* x, TDesc t, int N, int D, int H, int W, int C, unsigned* slot, hipStream_t st);
 int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const float* s2, const float* t2, int act2, float slope2,
                          int N, int C, int D, int H, int W, hipStream_t st);

@@ -16,6 +16,7 @@
 //
 // LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes.
 #pragma once
+#include <type_traits>
 #include <cstdlib>
 #include "common.h"
 #ifdef CS_TIMELINE
@@ -252,6 +253,9 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     if constexpr (ST != 0) {
         // ---------------- static shape: the K-steps of a chunk are fully unrolled
         constexpr int NT = SS::KD * SS::KH * SS::KW, NS = NT * KH32;
+        // kernels that carry the paired-tap body for a ragged last chunk (the 256-position tiles of the hourglass tail, the mask
+        // conv and the first encoder block)
+        constexpr bool RAGK = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8) && MODE == MODE_STD;
         constexpr int PFS = NS < 3 ? NS : 3;      // weight ring depth; the ring is re-primed at every chunk
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
         u4_t wr[PFS][WCH];
@@ -268,7 +272,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         __syncthreads();
         TL_STAMP(2);
         if (DB && cc_lo + 1 < cc_hi) stage_halo(1, (cc_lo + 1) * CK);
-        for (int cc = cc_lo; cc < cc_hi; ++cc) {
+        // head of a chunk: prime the weight ring, then wait for / re-issue the halo staging; returns the chunk's LDS buffer
+        auto chunk_head = [&](int cc) -> const unsigned char* {
             // prime the ring with this chunk's first steps before waiting on the halo: both latencies overlap
 #pragma unroll
             for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
@@ -282,23 +287,43 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                     __syncthreads();
                 }
             }
-            const unsigned char* hb = smem + (size_t)(DB ? ((cc - cc_lo) & 1) : 0) * HV * VS;
-            // Software-pipelined operand fetch: the position fragments are split in two halves; while the MFMAs of one half
-            // run, the ds_reads of the other half (of this step or of the next one) are in flight, so no LDS round trip is
-            // exposed in steady state and no extra registers are needed.
+            return smem + (size_t)(DB ? ((cc - cc_lo) & 1) : 0) * HV * VS;
+        };
+        // Software-pipelined operand fetch: the position fragments are split in two halves; while the MFMAs of one half
+        // run, the ds_reads of the other half (of this step or of the next one) are in flight, so no LDS round trip is
+        // exposed in steady state and no extra registers are needed.
+        // RAG (the ragged last chunk of a layer with Cin % 32 == 16, ConvParams::ragged): the 16 real channels of two taps that
+        // are neighbours along the row share one 32-deep MFMA - lanes l4 < 2 read tap t, lanes l4 >= 2 the same two slots of tap
+        // t + 1 (their fragment address is shifted by one voxel / halo row minus two slots); the weights of this chunk were
+        // re-packed the same way (pair_ragged_kernel).  The odd tap of a row runs as an ordinary step (its upper 16 channels are
+        // the staged zeros).
+        auto run_chunk = [&](int cc, const unsigned char* hb, auto rag_t) {
+            constexpr bool RAG = decltype(rag_t)::value;
             constexpr int HA = WPX / 2;                    // fragments in the first half
+            constexpr int PK = SS::KW > 1 ? SS::KW : SS::KH, SPR = PK / 2 + PK % 2;      // taps per row, steps per row
+            constexpr int NSC = RAG ? (NT / PK) * SPR : NS;
+            auto tap_of = [&](int st) -> int { return RAG ? (st / SPR) * PK + 2 * (st % SPR) : st / KH32; };
+            auto paired = [&](int st) -> bool { return RAG && (st % SPR) < PK / 2; };
             auto toff_of = [&](int st) -> int {
-                const int tap = st / KH32, half = st % KH32;
+                const int tap = tap_of(st), half = RAG ? 0 : st % KH32;
                 return (((tap / (SS::KW * SS::KH)) * SHH + (tap / SS::KW) % SS::KH) * SHW + tap % SS::KW) * VS + half * 64;
             };
+            // lane part of a paired fragment's address
+            int abP[RAG ? WPX : 1];
+            if constexpr (RAG) {
+                const int pd = (l4 >= 2) ? (SS::KW > 1 ? VS : SHW * VS) - 32 : 0;
+#pragma unroll
+                for (int pi = 0; pi < WPX; ++pi) abP[pi] = abase[pi] + pd;
+            }
+            auto ab_of = [&](int pi, int st) -> int { return paired(st) ? abP[RAG ? pi : 0] : abase[pi]; };
             h8_t afA[HA > 0 ? HA : 1], afB[WPX - HA];
 #pragma unroll
-            for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + abase[pi] + toff_of(0));
+            for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + ab_of(pi, 0) + toff_of(0));
 #pragma unroll
-            for (int st = 0; st < NS; ++st) {
+            for (int st = 0; st < NSC; ++st) {
                 const int toff = toff_of(st);
 #pragma unroll
-                for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + abase[pi] + toff);
+                for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + ab_of(pi, st) + toff);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
@@ -307,9 +332,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                         acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afA[pi],
                                                                              acc[ci][pi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < NS) {
+                if (st + 1 < NSC) {
 #pragma unroll
-                    for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + abase[pi] + toff_of(st + 1));
+                    for (int pi = 0; pi < HA; ++pi)
+                        afA[pi] = *(const h8_t*)(hb + ab_of(pi, st + 1) + toff_of(st + 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -319,8 +345,14 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                         acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afB[pi - HA],
                                                                              acc[ci][pi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + PFS < NS) wload_at(wr[st % PFS], cc, st + PFS);
+                if (st + PFS < NSC) wload_at(wr[st % PFS], cc, st + PFS);
             }
+        };
+        // the ragged chunk is peeled off the loop (inside it, the two bodies together cost the 160-wide kernels 500-650 bytes of scratch)
+        const bool rag = RAGK && p.ragged && cc_hi == nck;
+        for (int cc = cc_lo; cc < cc_hi - (rag ? 1 : 0); ++cc) { const unsigned char* hb = chunk_head(cc); run_chunk(cc, hb, std::false_type{}); }
+        if constexpr (RAGK) {
+            if (rag) { const unsigned char* hb = chunk_head(cc_hi - 1); run_chunk(cc_hi - 1, hb, std::true_type{}); }
         }
     } else {
         // This wave's K-step sequence: for every chunk cc, "fine" steps j = j0, j0+SKS, ... < ntaps*nhalf(cc) with
@@ -523,6 +555,13 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if ((1 << lgS) > BM) { cs_set_error("conv_halo: spatial tile exceeds BM"); return -1; }
     if (MODE == MODE_SPADE && (1 << lgS) != BM) { cs_set_error("conv_halo: SPADE launches must tile within one sample"); return -1; }
     if (MODE == MODE_SPADE && p.res_f32) { cs_set_error("conv_halo: the tensor a SPADE launch modulates is fp16"); return -1; }
+    if (p.ragged) {
+        constexpr bool ragk = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8) && MODE == MODE_STD;
+        if (!ragk || SK || p.Cin % 32 != 16 || p.sk_out || p.hilo || p.cg > 0) {
+            cs_set_error("conv_halo: paired-tap weights (ragged) need the 256-position 32-channel static kernels and Cin %% 32 == 16");
+            return -1;
+        }
+    }
     if (p.wslot && (1 << lgS) != BM) { cs_set_error("conv_halo: per-sample weight sets need tiles within one sample"); return -1; }
     const int TN = BM >> lgS;
     const long HV = (long)TN * ((1 << p.lgTD) + p.KD - 1) * ((1 << p.lgTH) + p.KH - 1) * ((1 << p.lgTW) + p.KW - 1);

@@ -32,13 +32,14 @@ constexpr long VOL = (long)FD * FH * FW * FC;                 // 2,097,152 eleme
 constexpr long VOX = (long)FD * FH * FW;                      // 65,536 voxels
 constexpr int IMG = 256;
 
-struct Blob { void* p = nullptr; size_t bytes = 0; };
+struct Blob { void* p = nullptr; size_t bytes = 0; bool paired = false; };     // paired: launch_pair_ragged already ran on it
 
 struct ConvL {            // one packed convolution layer
     const half_t* w = nullptr;
     const float* b = nullptr;
     int Cin = 0, Cout_pad = 0, Cout = 0, KD = 1, KH = 1, KW = 1;
     double macs_per_pos = 0;   // logical (reference) Cin*Cout*taps, for FLOP accounting
+    bool ragged = false;       // Cin % 32 == 16 and the last chunk's weights re-packed for paired taps (ConvParams::ragged)
     std::string name;
 };
 
@@ -171,7 +172,7 @@ int get_conv(cs_engine* e, const std::string& n, int Cin, int Cout_pad, int Cout
     L->b = nullptr;
     if (bias_len > 0) { TRY(need(e, n + ".b", (size_t)bias_len * sizeof(float), &p)); L->b = (const float*)p; }
     L->Cin = Cin; L->Cout_pad = Cout_pad; L->Cout = Cout; L->KD = KD; L->KH = KH; L->KW = KW;
-    L->macs_per_pos = macs;
+    L->macs_per_pos = macs; L->ragged = false;
     L->name = n;
     return 0;
 }
@@ -223,7 +224,7 @@ ConvCall mk(const ConvL& L, const void* in, TDesc ind, int N, int D, int H, int 
     p.N = N; p.D = D; p.H = H; p.W = W; p.inD = D;
     p.Cin = L.Cin; p.nchunks = (L.Cin + 31) / 32; p.up_shift = up_shift;
     p.KD = L.KD; p.KH = L.KH; p.KW = L.KW; p.PD = L.KD / 2; p.PH = L.KH / 2; p.PW = L.KW / 2;
-    p.wgt = L.w; p.Cout_pad = L.Cout_pad; p.Cout = L.Cout;
+    p.wgt = L.w; p.Cout_pad = L.Cout_pad; p.Cout = L.Cout; p.ragged = L.ragged;
     p.bias = L.b;
     p.ps_stride = 1;
     c.macs_per_pos = L.macs_per_pos;
@@ -254,6 +255,12 @@ int pick_cfg(int Cout_pad)
 // tile configuration of the 32->32 3x3x3 convs on the [H][W][D][C] volumes: 256 positions (4x4x16) x 32 channels; 128-position
 // tiles measured slower (more halo re-reads than the extra occupancy returns)
 int cfg_v32() { return CFG_H_256x32; }
+
+// 256-position tiles of the hourglass tail / mask conv (160 channels) and the first encoder block (64 channels); with them the
+// ragged last chunk of those layers (Cin 144 / 112) runs paired taps (CANONSWAP_RAGGED=0: A/B knob)
+bool big160() { static const bool v = [] { const char* s = getenv("CANONSWAP_TILE256x160"); return s ? atoi(s) != 0 : true; }(); return v; }
+bool enc256() { static const bool v = [] { const char* s = getenv("CANONSWAP_ENC256"); return s ? atoi(s) != 0 : true; }(); return v; }
+bool ragged_on() { static const bool v = [] { const char* s = getenv("CANONSWAP_RAGGED"); return s ? atoi(s) != 0 : true; }(); return v; }
 
 // ConvParams::xcd_map of every engine launch (A/B knob CANONSWAP_XCD_MAP=0|1|2)
 int xcd_map_default()
@@ -301,7 +308,14 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
     e->flops += fl;
     // MFMA work actually issued: packed (padded) channel counts and the taps this launch really runs
-    e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * (c.p.nchunks * 32.0) * c.p.KD * c.p.KH * c.p.KW;
+    {
+        double ksteps = (double)c.p.nchunks * c.p.KD * c.p.KH * c.p.KW;      // 32-deep K-steps per output element
+        if (c.p.ragged) {                                                    // paired taps in the last chunk
+            const int NT = c.p.KD * c.p.KH * c.p.KW, PK = c.p.KW > 1 ? c.p.KW : c.p.KH;
+            ksteps -= NT - (NT / PK) * (PK / 2 + PK % 2);
+        }
+        e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps;
+    }
     if (halo_enabled() && c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
@@ -465,8 +479,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         (void)cin;
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_pre, FD, S, S, cout[i]);
-        static const bool enc256 = [] { const char* s = getenv("CANONSWAP_ENC256"); return s ? atoi(s) != 0 : true; }();   // 0.65 -> 0.47 ms per 16 frames
-        if (i == 0 && enc256) c.hcfg = CFG_H_256x64;        // 64 channels at 64x64: 256-position tiles (128 positions per wave)
+        if (i == 0 && enc256()) c.hcfg = CFG_H_256x64;      // 64 channels at 64x64: 256-position tiles (0.65 -> 0.47 ms per 16 frames)
         TRY(go(e, c, st));
         TDesc o = dhwc(e->dm_l[i + 1] + skip_off[i + 1], FD, S / 2, S / 2, lw[i + 1]);
         TRY(e->run(1, st, [&] { return launch_avgpool(e->dm_pre, B, FD, S, S, cout[i], o, st); }, "avgpool"));
@@ -499,12 +512,11 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     t.p.act0 = ACT_RELU; t.p.out0 = dhwc(e->dm_pred, FD, 64, 64, 144);
     // 160-wide tiles: 128 positions (two workgroups per CU) or 256 positions (one per CU, half the weight bytes per MFMA)
     // (tail 1.78 -> 1.29 ms, mask 2.63 -> 2.01 ms per 16 frames, profiles/r02_timeline_*.txt; CANONSWAP_TILE256x160=0 is the A/B knob)
-    static const bool big160 = [] { const char* s = getenv("CANONSWAP_TILE256x160"); return s ? atoi(s) != 0 : true; }();
-    t.hcfg = big160 ? CFG_H_256x160 : CFG_H_128x160;
+    t.hcfg = big160() ? CFG_H_256x160 : CFG_H_128x160;
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
-    m.hcfg = big160 ? CFG_H_256x160 : CFG_H_128x160;
+    m.hcfg = big160() ? CFG_H_256x160 : CFG_H_128x160;
     {   // no halo along W (KW = 1): a 2x8x8 tile stages 392 halo voxels per 128 positions, 8x8x2 would stage 896
         static const bool wide = getenv("CANONSWAP_MASK_TILE8") != nullptr;
         TRY(go(e, m, st, wide ? 8 : 2, 8));
@@ -917,7 +929,7 @@ extern "C" int cs_upload(cs_engine* e, const char* name, const void* host_ptr, s
     Blob& b = e->blobs[name];
     if (b.p) { hipFree(b.p); b.p = nullptr; }
     CS_CHECK_HIP(hipMalloc(&b.p, nbytes));
-    b.bytes = nbytes;
+    b.bytes = nbytes; b.paired = false;
     CS_CHECK_HIP(hipMemcpy(b.p, host_ptr, nbytes, hipMemcpyHostToDevice));
     e->finalized = false;
     return 0;
@@ -990,6 +1002,16 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     }
     TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));
+    if (ragged_on()) {      // Cin 144 / 144 / 112: the 16 real channels of the last chunk as paired taps (in place, once per upload)
+        auto pair = [&](ConvL& L) -> int {
+            Blob& bl = e->blobs[L.name + ".w"];          // exists: get_conv found it
+            if (!bl.paired && launch_pair_ragged(const_cast<half_t*>(L.w), L.Cout_pad, (L.Cin + 31) / 32, L.KD, L.KH, L.KW, 0)) return -1;
+            bl.paired = true; L.ragged = true;
+            return 0;
+        };
+        if (big160()) { TRY(pair(e->w_tail)); TRY(pair(e->w_mask)); }
+        if (enc256()) TRY(pair(e->w_enc[0]));
+    }
     TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
     TRY(get_conv(e, "W.occp", 16 * 160, 32, 16, 1, 7, 1, 0, 2272.0 * 49, &e->w_occ));
     { const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
@@ -1410,12 +1432,18 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
         set_tile(p, BM, d->tile_w ? d->tile_w : (is3d ? 8 : 16), d->tile_h ? d->tile_h : (is3d ? 8 : BM / 16));
         const int ck = d->ck ? d->ck : ((!is3d && p.Cin % 64 == 0) ? 64 : 32);
         p.xcd_map = d->xcd_map > 0 ? d->xcd_map - 1 : xcd_map_default();
+        p.ragged = d->ragged;
         return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);
     }
     c.cfg = d->cfg >= 0 ? d->cfg : pick_cfg(p.Cout_pad);
     const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
     set_tile(p, BM, d->tile_w ? d->tile_w : 16, d->tile_h ? d->tile_h : BM / 16);
     return launch_conv(p, c.cfg, c.mode, (hipStream_t)stream);
+}
+
+extern "C" int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream)
+{
+    return launch_pair_ragged((half_t*)w, Cout_pad, nchunks, KD, KH, KW, (hipStream_t)stream);
 }
 
 extern "C" int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,

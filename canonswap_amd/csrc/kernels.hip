@@ -818,6 +818,46 @@ int launch_splitk_finish(const ConvParams& p, hipStream_t st)
 
 
 // ------------------------------------------------------------------------------------------------
+// Ragged last chunk (Cin % 32 == 16): rows of the chunk are re-packed so that K-step s of the chunk multiplies the 16 real channels
+// of tap t(s) (k 0..15) and of tap t(s) + 1 (k 16..31) where both lie in one row of PK taps; the odd tap of a row keeps its row
+// (k 16..31 are the zero pad channels).  Step order as conv_halo_kernel.h walks it: row-major, pairs first.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pair_ragged_kernel(const half_t* __restrict__ src, half_t* __restrict__ dst, int Cout_pad, int NT,
+                                                          int PK)
+{
+    const int SPR = PK / 2 + PK % 2, NSR = (NT / PK) * SPR;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)NSR * Cout_pad * 32) return;
+    const int k = (int)(i & 31);
+    const int c = (int)((i >> 5) % Cout_pad);
+    const int s = (int)((i >> 5) / Cout_pad);
+    const int tapA = (s / SPR) * PK + 2 * (s % SPR);
+    const bool paired = (s % SPR) < PK / 2;
+    const long a = ((long)tapA * Cout_pad + c) * 32, b = ((long)(tapA + 1) * Cout_pad + c) * 32;
+    dst[i] = !paired ? src[a + k] : (k < 16 ? src[a + k] : src[b + k - 16]);
+}
+
+int launch_pair_ragged(half_t* w, int Cout_pad, int nchunks, int KD, int KH, int KW, hipStream_t st)
+{
+    const int NT = KD * KH * KW, PK = KW > 1 ? KW : KH;
+    if (nchunks < 1 || PK < 2 || NT % PK) { cs_set_error("pair_ragged: unsupported shape"); return -1; }
+    const size_t n = (size_t)NT * Cout_pad * 32;
+    half_t* last = w + (size_t)(nchunks - 1) * n;
+    half_t* tmp = nullptr;
+    CS_CHECK_HIP(hipMalloc((void**)&tmp, n * sizeof(half_t)));
+    hipError_t r = hipMemcpyAsync(tmp, last, n * sizeof(half_t), hipMemcpyDeviceToDevice, st);
+    if (r == hipSuccess) {
+        const int NSR = (NT / PK) * (PK / 2 + PK % 2);
+        hipLaunchKernelGGL(pair_ragged_kernel, dim3(cdiv((long)NSR * Cout_pad * 32, 256)), dim3(256), 0, st, tmp, last, Cout_pad, NT, PK);
+        r = hipGetLastError();
+    }
+    if (r == hipSuccess) r = hipStreamSynchronize(st);
+    hipFree(tmp);
+    if (r != hipSuccess) { cs_set_error("pair_ragged: %s", hipGetErrorString(r)); return -1; }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // debug: largest magnitude of an fp16 channels-last tensor view (CANONSWAP_AMAX=1 in a profiled step: how close every layer's
 // stored activations come to the fp16 range limit 65504).  slot: float bits, maximum by integer compare (values are >= 0)
 // ------------------------------------------------------------------------------------------------

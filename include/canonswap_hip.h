@@ -139,8 +139,13 @@ typedef struct cs_conv_desc {
     int tile_w, tile_h;       /* 0 = auto */
     int ck;                   /* conv_halo channel chunk: 0 auto, 32 or 64 */
     int xcd_map;              /* conv_halo workgroup -> tile mapping: 0 engine default, k > 0 forces mapping k - 1 (common.h) */
+    int ragged;               /* Cin % 32 == 16 and wgt went through cs_op_pair_ragged: paired taps in the last chunk (cfg 19 / 20 only) */
 } cs_conv_desc;
 int cs_op_conv(const cs_conv_desc* d, void* stream);
+/* in place: re-pack the last 32-channel chunk of a packed conv weight [chunks * taps][Cout_pad][32] (Cin % 32 == 16) so that two
+ * taps that are neighbours along the row share one 32-deep K-step (what the engine does for the hourglass tail, the mask conv and the
+ * first encoder block at load time; dense_motion.py:88, util.py:185-190,261-263) */
+int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream);
 int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,
                         void* stream);
 /* per-(n,c) mean and 1/sqrt(var+eps) of a [N][P][C] tensor; partials: scratch of cs_op_chan_stats_partial_floats floats */

@@ -21,7 +21,7 @@ def strides_cl(t):
 
 def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0="none", slope0=0.0, res=None, res_shift=0,
          pixscale=None, ps_stride=1, out0=None, s2=None, t2=None, act1="none", slope1=0.0, out1=None, stats=None,
-         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0, xcd_map=None):
+         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0, xcd_map=None, ragged=False):
     """x: [N, D, H, W, C] fp16 view (C contiguous). out0/out1/res: 5-D channels-last views. k = (KD, KH, KW)."""
     lib = _lib.load()
     d = _lib.ConvDesc()
@@ -57,8 +57,17 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
     d.tile_w, d.tile_h = tile
     d.ck = ck
     d.xcd_map = 0 if xcd_map is None else xcd_map + 1
+    d.ragged = int(ragged)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.cs_op_conv(C.byref(d), st), "cs_op_conv")
+
+
+def pair_ragged(wpacked, cout_pad, cin, k):
+    """In place: the engine's load-time re-packing of the last chunk of a Cin % 32 == 16 layer (paired taps)."""
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.cs_op_pair_ragged(C.c_void_p(wpacked.data_ptr()), cout_pad, (cin + 31) // 32, k[0], k[1], k[2], st), "cs_op_pair_ragged")
+    return wpacked
 
 
 def packed_weight(w, cout_pad, device):

@@ -326,3 +326,34 @@ def test_conv_256x64_tile():
         assert ops.rel_err(_from_cl(out), ref) < 3e-3
         outs.append(out.cpu())
     assert torch.equal(outs[0], outs[1])        # same K order per output element: bit-identical across tile shapes
+
+
+@pytest.mark.parametrize("k,tile,cfg,cout_pad,cin_real,cin", [((3, 3, 3), (8, 8), 19, 160, 142, 144), ((7, 7, 1), (2, 8), 19, 160, 142, 144),
+                                                              ((3, 3, 3), (8, 8), 20, 64, 110, 112)])
+def test_conv_ragged_last_chunk_paired_taps(k, tile, cfg, cout_pad, cin_real, cin):
+    """Cin % 32 == 16 (hourglass tail / mask conv 144, first encoder block 112): the 16 real channels of the last chunk of two taps
+    that are neighbours along the row share one 32-deep MFMA step (ConvParams::ragged, weights re-packed by cs_op_pair_ragged as the
+    engine does at load time).  Same convolution - against the fp32 reference and against the unpaired launch."""
+    import hip_ops as ops
+    r = _rng(51 + cfg + k[0])
+    N, D, H, W = 3, 16, 16, 16
+    Cout = cout_pad - 10 if cout_pad == 160 else cout_pad
+    x = _randn(r, N, cin_real, D, H, W)
+    w = _randn(r, Cout, cin_real, *k, scale=1.0 / np.sqrt(cin_real * np.prod(k)))
+    b = _randn(r, Cout, scale=0.1)
+    ref = F.relu(_ref_conv(x, w, b, tuple(kk // 2 for kk in k)))
+    buf = torch.zeros(N, D, H, W, cin, dtype=torch.float16, device=DEV)
+    buf[..., :cin_real] = _to_cl(x).to(DEV)
+    bp = torch.zeros(cout_pad); bp[:Cout] = b
+    outs = []
+    for ragged in (False, True):
+        wp = ops.packed_weight(w, cout_pad, DEV)
+        if ragged:
+            ops.pair_ragged(wp, cout_pad, cin, k)
+        out = torch.zeros(N, D, H, W, cout_pad, dtype=torch.float32, device=DEV)
+        ops.conv(buf, wp, cout_pad, cout_pad, k, cin=cin, bias=bp.to(DEV), act0="relu", out0=out, cfg=cfg, tile=tile, ragged=ragged)
+        torch.cuda.synchronize()
+        assert ops.rel_err(_from_cl(out[..., :Cout]), ref) < 2e-3
+        assert Cout == cout_pad or float(out[..., Cout:].abs().max()) == 0.0
+        outs.append(out.cpu())
+    assert ops.rel_err(outs[1], outs[0]) < 1e-5          # fp32 accumulation, another order within the last chunk

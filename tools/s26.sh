@@ -1,0 +1,3 @@
+#!/bin/bash
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 5
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
