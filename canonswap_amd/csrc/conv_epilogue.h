@@ -225,8 +225,8 @@ _Pragma("unroll") \
        carry a residual and 80 more live registers would cost them an occupancy step). */ \
     constexpr bool EP_PF = (WCH != 5); \
     /* position blocks fetched per round: the whole tile where the register budget allows (no scratch, same occupancy step - \
-       checked with tools/kernel_resources.py), else groups of 4 (128x128 tiles held to 168 registers) or 2 (128x256 non-blend) */ \
-    constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? 2 : 4))); \
+       checked with tools/kernel_resources.py), else groups of 4 (128x128 tiles held to 168 registers), 2 (128x256 non-blend) or 1 (128x256 with 32 statistics accumulators) */ \
+    constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? (EP_STAT ? 1 : 2) : 4))); \
     constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
     const bool ep_fetch = EP_PF && p.res.p != nullptr; \
     /* channel pairs (EP_PAIR): fp16 tensors whose pointer and strides keep 8 channels 16-byte aligned get one access per pair */ \

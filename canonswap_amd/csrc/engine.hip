@@ -280,11 +280,17 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     const int Cout_pad = p.Cout_pad;
     if (mode == MODE_PIXSHUF) return CFG_H_256x16;
     // 128 positions x 256 channels (64 channels per wave) only exists as the fully unrolled 3x3 / 16x8-tile kernel
-    // 2 resident 128x256 workgroups win only for the T blend convs (N = 1024, 4 channel blocks per tile: +4.7 %); everywhere
-    // else 3 resident 128x128 workgroups are 4-14 % faster (G 3x3 convs, fc, F down-blocks) - measured per layer with tools/cmp_layers.py
+    // 2 resident 128x256 workgroups: the T blend convs (N = 1024, 4 channel blocks per tile: +4.7 %).  In round 1 three resident
+    // 128x128 workgroups were 4-14 % faster everywhere else (G 3x3 convs, fc, F down-blocks; tools/cmp_layers.py); see below
     // (below 3 frames a 128x256 launch is 128 workgroups or fewer: 128x128 tiles put one on every CU; same K order, same bits)
     if (mode == MODE_TBLEND && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 32 == 0 &&
         (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
+    // ... and, since the round-2 epilogue / addressing work, for the other 3x3 convs with 256 or more output channels (G 512->512 with
+    // and without statistics, R's 512-channel pair, W.third): +0.7 % on the step, the same per-64-position statistics, the same bits
+    // (CANONSWAP_G256=0: the 128x128 tiles; 1: only the convs without statistics)
+    static const int g256 = [] { const char* s = getenv("CANONSWAP_G256"); return s ? atoi(s) : 2; }();
+    if (g256 && (mode == MODE_STD || (g256 > 1 && mode == MODE_STDSTAT)) && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 &&
+        p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 && (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     if (Cout_pad % 128 == 0) {
         // a launch of 128 or fewer 128x128 workgroups leaves half of the 256 CUs idle (one frame: the 512-channel 3x3 convs at 64x64
         // are 32 x 4): 128x64 tiles put a workgroup on every CU.  Same K order per output element, same bits.
