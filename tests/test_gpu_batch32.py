@@ -45,6 +45,18 @@ def test_b32_frames_bit_equal_to_b1(swapper, batch, out32, i):
     assert torch.equal(r["out_u8"].cpu()[0], out32[1][i])
 
 
+@pytest.mark.parametrize("n", [2, 3, 4, 7, 16])
+def test_tile_policy_boundaries_bit_equal(swapper, batch, out32, n):
+    """The tile shapes change with the number of frames in a call (128x64 tiles for launches that would leave CUs idle, 128x128 below
+    three frames and 128x256 from there for T and the wide G / R convs, workgroups spanning two samples where a sample has fewer
+    positions than a tile): frames 0 .. n-1 of an n-frame call == the same frames of the 32-frame call, bit for bit - every output
+    element keeps its K order and the norm statistics are per 64 positions in every tile shape."""
+    args, idv = batch
+    r = swapper.swap_frames(args["img"][:n].cuda(), args["x_t"][:n].cuda(), args["x_can"][:n].cuda(), idv.cuda(), want_u8=True)
+    assert torch.equal(r["out"].cpu(), out32[0][:n])
+    assert torch.equal(r["out_u8"].cpu(), out32[1][:n])
+
+
 def test_b32_psnr_vs_oracle(state_dicts, batch, out32):
     """frames 0 and 31 of the B = 32 call against the fp32 CPU oracle (about 15 s of CPU)."""
     from oracle import canonswap_ref as O
