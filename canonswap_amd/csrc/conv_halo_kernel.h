@@ -256,7 +256,13 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         // kernels that carry the paired-tap body for a ragged last chunk (the 256-position tiles of the hourglass tail, the mask
         // conv and the first encoder block)
         constexpr bool RAGK = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8) && MODE == MODE_STD;
-        constexpr int PFS = NS < 3 ? NS : 3;      // weight ring depth; the ring is re-primed at every chunk
+        // weight ring depth; the ring is re-primed at every chunk.  Three steps cover an L2 round trip where a step is 16-40 MFMAs; the
+        // 16- and 32-channel tiles run 2-4 MFMAs per step and were bound by that latency (T's mask conv: 80 us for 134 MB): 8 steps
+#ifdef CS_PFS3
+        constexpr int PFS = NS < 3 ? NS : 3;
+#else
+        constexpr int PFS = NS < 3 ? NS : (WCH * WPX <= 4 ? (NS < 8 ? NS : 8) : 3);
+#endif
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
         u4_t wr[PFS][WCH];
         // In this fully unrolled body hipcc counts vmcnt / lgkmcnt exactly (the only conservative drain sits at the chunk
