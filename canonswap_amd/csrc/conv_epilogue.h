@@ -125,6 +125,7 @@ __device__ __forceinline__ constexpr int ep_pair_of(int mode, int wch)
 // EP_HEAVY (constexpr bool, in scope): this instantiation also carries sigmoid / GELU for act0 (launchers refuse those activations
 // on the others); act1 is always one of none / ReLU / LeakyReLU.
 // Expects in scope: p, ep_acc[WCH][EP_WPX] (f4_t), ep_wpx (position-block index of this wave), EP_WPX, n0, tw, th, td, tn,
+// l15p (the position 0..15 of its blocks this lane works on: l15, or the conv_halo kernels' bank-conflict permutation of it),
 // lgTW, lgTH, lgTD, lgS, mW, mH, mD (the tile decomposition: compile-time constants in the static-shape kernels, which turns the
 // per-block coordinates below into constants), wch, l15, l4, tile_lin (linear index of the position tile) and the template constants
 // WCH, BM, MODE, EP_EARLY (+ ep_xpre from CONV_EPILOGUE_EARLY_FETCH; false elsewhere), EP_PAIR (ep_pair_of(MODE, WCH) where the kernel permutes its weight rows accordingly, else 0).
@@ -143,7 +144,7 @@ __device__ __forceinline__ constexpr int ep_pair_of(int mode, int wch)
     ep_u2_t ep_xpre[EP_EARLY ? EP_WPX0 : 1][EP_EARLY ? (WCH + 1) / 2 : 1]; \
     if constexpr (EP_EARLY) { \
         int xlw, xlh, xld, xln; \
-        { int t = l15; xlw = t & mW; t >>= lgTW; xlh = t & mH; t >>= lgTH; xld = t & mD; t >>= lgTD; xln = t; } \
+        { int t = l15p; xlw = t & mW; t >>= lgTW; xlh = t & mH; t >>= lgTH; xld = t & mD; t >>= lgTD; xln = t; } \
         const int xrs = p.res_shift, xnb = tn * (BM >> lgS); \
         const unsigned xlane = (unsigned)((xnb + xln) * (int)p.res.sN + __mul24((td << lgTD) + xld, (int)p.res.sD) + \
                                           __mul24(((th << lgTH) + xlh) >> xrs, (int)p.res.sH) + __mul24(((tw << lgTW) + xlw) >> xrs, (int)p.res.sW)); \
@@ -241,7 +242,7 @@ _Pragma("unroll") \
        Offsets are 32-bit (launchers refuse tensors of 2^31 elements) and unsigned, which lets the loads / stores use the \
        SGPR-base + VGPR-offset form. */ \
     int ep_lw, ep_lh, ep_ld, ep_ln; \
-    { int t = l15; ep_lw = t & mW; t >>= lgTW; ep_lh = t & mH; t >>= lgTH; ep_ld = t & mD; t >>= lgTD; ep_ln = t; } \
+    { int t = l15p; ep_lw = t & mW; t >>= lgTW; ep_lh = t & mH; t >>= lgTH; ep_ld = t & mD; t >>= lgTD; ep_ln = t; } \
     const int ep_w0 = tw << lgTW, ep_h0 = th << lgTH, ep_d0 = td << lgTD, ep_nb = tn * (BM >> lgS); \
     const int ep_rs = (MODE == MODE_SPADE) ? p.res_shift : 0; \
     /* per-axis products as 24-bit multiplies (full rate; coordinates are small, launchers refuse axis strides >= 2^23); the \

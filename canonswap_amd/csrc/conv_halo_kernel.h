@@ -73,6 +73,50 @@ template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 2, KW = 1
 template <> struct StaticShape<14> { static constexpr int KD = 1, KH = 1, KW = 2, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<15> { static constexpr int KD = 1, KH = 1, KW = 1, LW = 4, LH = 3, LD = 0; };
 
+// ---- LDS image of the halo and the bank conflicts of the fragment reads (model and search: tools/lds_bank_search.py).
+// ds_read_b128 serves a wave in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) over 64 banks of 4 bytes.  A lane
+// (l15 = position, l4 = k slot) reads voxel(position) * VS + l4 * 16, so with one pad slot (voxel stride 5 / 9 slots of 16 bytes) every
+// group hits half of its bank quads twice - three times where a position block is rows of 8 or 4 voxels - which is what the counters
+// show (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.50-0.67, profiles/r02_g_wave_state.txt).  Two levers:
+//   * which of the 16 positions of a block a lane works on is free (the epilogue uses the same map): a bit permutation of the lane
+//     index takes the volume tiles from 3 to 2 cycles per group at the same stride (halo_lane_pos);
+//   * a voxel stride of 6 / 10 slots (two pad slots) is conflict-free for 16 consecutive voxels at any alignment and, with the
+//     permutation, for the volume tiles; it costs 20 % / 11 % more LDS and is used where the occupancy stays the same (halo_pad).
+template <int CK, int WPX, int WCH, int WVP, int ST, int MODE> constexpr int halo_pad()
+{
+#ifdef CS_LDS_V1
+    return 1;
+#else
+    if (CK == 64 && WCH == 4 && WPX == 8 && ST == 1) return 2;                       // 128x256 tiles (T, wide G / R convs): 2 workgroups per CU
+    if (CK == 32 && WCH == 5 && WPX == 8 && (ST == 7 || ST == 8)) return 2;           // 256x160 tiles: 1 workgroup per CU
+    // SPADE gamma/beta convs (128x128, three workgroups per CU): the 64-channel image would not fit three times with two pad slots
+    // (173 KB) and measured slower at two workgroups; with 32-channel chunks it does (104 KB) - the engine launches them that way
+    if (CK == 32 && WCH == 2 && WPX == 8 && ST == 1 && MODE == MODE_SPADE) return 2;
+#ifdef CS_LDS_V32
+    if (CK == 32 && WCH == 2 && WPX == 4 && WVP == 4 && ST == 3) return 2;            // 256x32 volume tiles: 3 -> 2 workgroups per CU
+#endif
+    return 1;
+#endif
+}
+// pieces per thread whose source offsets are kept in registers = ceil(halo voxels * slots per voxel / 256)
+template <int ST, int PAD> constexpr int halo_hi()
+{
+    if (PAD == 2) return ST == 3 ? 16 : ((ST == 7 || ST == 8) ? 15 : 8);
+    return ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8) ? 13 : (ST == 12 ? 9 : 8));
+}
+// position (0..15 within its block) that lane l15 works on
+template <int ST, int PAD> __device__ __forceinline__ int halo_lane_pos(int l)
+{
+#ifdef CS_LDS_V1
+    return l;
+#else
+    using SS = StaticShape<ST>;
+    if (ST == 0 || SS::KW != 3 || SS::LW > 3 || SS::LW < 2) return l;
+    if (SS::LW == 2 && PAD == 2) return ((l & 1) << 1) | ((l & 2) << 2) | ((l >> 2) & 1) | ((l & 8) >> 1);      // bits (1,3,0,2)
+    return ((l & 1) << 1) | ((l & 2) << 1) | ((l >> 2) & 1) | (l & 8);                                          // bits (1,2,0,3)
+#endif
+}
+
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 // Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
 // unrolled 128x128 tiles (<= 168 VGPRs, no scratch) -- for short-K convs a third workgroup hides the prologue / epilogue
@@ -85,10 +129,11 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP;
     constexpr int BN = WCH * 16 * WVC;
     constexpr int SL = CK / 8;           // 16-byte slots per voxel
-    constexpr int SLP = SL + 1;          // ... plus one pad slot (bank spreading; also fetched, from the zero page)
+    constexpr int PAD = halo_pad<CK, WPX, WCH, WVP, ST, MODE>();
+    constexpr int SLP = SL + PAD;        // ... plus the pad slot(s) (bank spreading; also fetched, from the zero page)
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
     // halo pieces per thread whose source offsets are kept in registers (the big halos of the mask conv / 4x4x16 tiles too)
-    constexpr int HI = ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8) ? 13 : (ST == 12 ? 9 : 8));
+    constexpr int HI = halo_hi<ST, PAD>();
     constexpr int KH32 = CK / 32;        // 32-channel K-steps per tap and chunk
     constexpr int PFD = 4;               // weight prefetch depth in K-steps
     constexpr int SKS = SK ? 4 : 1;      // K-step stride of one wave
@@ -106,6 +151,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wpx = SK ? 0 : wave % WVP, wch = SK ? 0 : wave / WVP;
     const int l15 = lane & 15, l4 = lane >> 4;
+    const int l15p = halo_lane_pos<ST, PAD>(l15);      // the position of its 16-position blocks this lane works on
 #ifdef CS_NO_PAIR                               // A/B builds (tools/build_variant.py)
     constexpr int EP_PAIR = 0;
 #else
@@ -214,7 +260,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     int abase[WPX];                      // LDS byte offset of this lane's position in the un-shifted halo window
 #pragma unroll
     for (int pi = 0; pi < WPX; ++pi) {
-        int m = wpx * WPX * 16 + pi * 16 + l15;
+        int m = wpx * WPX * 16 + pi * 16 + l15p;
         const int wl = m & mW; m >>= lgTW;
         const int hl = m & mH; m >>= lgTH;
         const int dl = m & mD; m >>= lgTD;
@@ -468,7 +514,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             const long mtot = (long)p.N * p.D * p.H * p.W;
 #pragma unroll
             for (int pi = 0; pi < WPX; ++pi) {
-                int m = wpx * WPX * 16 + pi * 16 + l15;
+                int m = wpx * WPX * 16 + pi * 16 + l15p;
                 const int w = (tw << lgTW) + (m & mW); m >>= lgTW;
                 const int h = (th << lgTH) + (m & mH); m >>= lgTH;
                 const int d = (td << lgTD) + (m & mD); m >>= lgTD;
@@ -538,7 +584,8 @@ template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK, int ST>
 static int launch_halo_st(const ConvParams& p, hipStream_t st)
 {
     constexpr int BM = SK ? WPX * 16 : WPX * 16 * WVP, BN = WCH * 16 * WVC;
-    constexpr int SLP = CK / 8 + 1, VS = SLP * 16;
+    constexpr int PAD = halo_pad<CK, WPX, WCH, WVP, ST, MODE>(), HI = halo_hi<ST, PAD>();
+    constexpr int SLP = CK / 8 + PAD, VS = SLP * 16;
     if (p.Cout_pad % BN != 0) { cs_set_error("conv_halo: Cout_pad %d not a multiple of the channel tile %d", p.Cout_pad, BN); return -1; }
     {   // in-tensor element offsets are kept in 32 bits inside the kernel, per-axis products in 24 (halo piece offsets; the epilogue's
         // tensors: ep_check_extents)
@@ -577,7 +624,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     constexpr bool big = (BM == 256 && WCH == 5);
     // (double-buffering the three 52 KB chunks of the split-precision volume convs - one workgroup per CU instead of three single-
     // buffered ones - measured 3 % slower on the whole step: profiles/r02_notes.md)
-    const bool db = nck > 1 && 2 * HV * VS <= (big ? 128 : 64) * 1024 && HV * SLP <= 256 * (big ? 13 : 8);
+    const bool db = nck > 1 && 2 * HV * VS <= (big || (WCH == 4 && PAD == 2) ? 128 : 64) * 1024 && HV * SLP <= 256 * HI;
     size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }

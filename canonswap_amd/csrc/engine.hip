@@ -333,7 +333,9 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             if (hcfg == CFG_H_128x32 || hcfg == CFG_H_128x16 || hcfg == CFG_H_SK128x32) wave_px = 32;
             c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (BM / wave_px);
         }
-        const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0) ? 64 : 32;
+        // SPADE convs run 32-channel chunks: their LDS image is then conflict-free at three workgroups per CU (conv_halo_kernel.h, halo_pad)
+        static const bool spade32 = [] { const char* s = getenv("CANONSWAP_SPADE_CK32"); return !s || atoi(s) != 0; }();
+        const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !(spade32 && c.mode == MODE_SPADE)) ? 64 : 32;
         c.p.xcd_map = xcd_map_default();
         {   // cross-workgroup split-K when the launch cannot fill the chip (single-frame latency: the deep hourglass levels run 8-64
             // workgroups that each stream megabytes of weights): plain bias + activation + one output only

@@ -39,6 +39,11 @@ void run(const ConvParams& p, int BM)
         const int wpx = wave % WVP, wch = wave / WVP;
         const int l15 = lane & 15, l4 = lane >> 4;
 #ifdef HARNESS_NO_PAIRING
+        const int l15p = l15;
+#else
+        const int l15p = ((l15 & 1) << 1) | ((l15 & 2) << 1) | ((l15 >> 2) & 1) | (l15 & 8);      // any bijection: the volume kernels' one
+#endif
+#ifdef HARNESS_NO_PAIRING
         constexpr int EP_PAIR = 0;
 #else
         constexpr int EP_PAIR = ep_pair_of(MODE, WCH);
@@ -48,7 +53,7 @@ void run(const ConvParams& p, int BM)
         f4_t acc[WCH][WPX];
         for (int ci = 0; ci < WCH; ++ci) for (int pi = 0; pi < WPX; ++pi) for (int r = 0; r < 4; ++r) {
             const int row = n0 + wch * WCH * 16 + ep_frag_row(EP_PAIR, ci) + ep_lane_row(EP_PAIR, l4 * 4 + r);
-            const int m = (wpx * WPX + pi) * 16 + l15;
+            const int m = (wpx * WPX + pi) * 16 + l15p;
             acc[ci][pi][r] = rnd((uint32_t)((tile * 1024 + m) * 2053 + row * 31 + 7));
         }
 #ifdef HARNESS_NO_PAIRING
