@@ -260,6 +260,10 @@ int cfg_v32() { return CFG_H_256x32; }
 // ragged last chunk of those layers (Cin 144 / 112) runs paired taps (CANONSWAP_RAGGED=0: A/B knob)
 bool big160() { static const bool v = [] { const char* s = getenv("CANONSWAP_TILE256x160"); return s ? atoi(s) != 0 : true; }(); return v; }
 bool enc256() { static const bool v = [] { const char* s = getenv("CANONSWAP_ENC256"); return s ? atoi(s) != 0 : true; }(); return v; }
+// SPADE gamma/beta convs with 128 or more modulated channels (Cout_pad % 256 == 0) on 128x256 tiles from three frames up: +0.5 % with the
+// conflict-free LDS image (neutral before it).  Those layers keep 64-channel chunks at every batch size (same K order, same bits); the
+// 64-channel ones (Cout_pad 128) run 32-channel chunks on 128x128 tiles.
+bool spade256() { static const bool v = [] { const char* s = getenv("CANONSWAP_SPADE256"); return !s || atoi(s) != 0; }(); return v; }
 bool ragged_on() { static const bool v = [] { const char* s = getenv("CANONSWAP_RAGGED"); return s ? atoi(s) != 0 : true; }(); return v; }
 
 // ConvParams::xcd_map of every engine launch (A/B knob CANONSWAP_XCD_MAP=0|1|2)
@@ -289,6 +293,8 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     // and without statistics, R's 512-channel pair, W.third): +0.7 % on the step, the same per-64-position statistics, the same bits
     // (CANONSWAP_G256=0: the 128x128 tiles; 1: only the convs without statistics)
     static const int g256 = [] { const char* s = getenv("CANONSWAP_G256"); return s ? atoi(s) : 2; }();
+    if (spade256() && mode == MODE_SPADE && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 &&
+        (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     if (g256 && (mode == MODE_STD || (g256 > 1 && mode == MODE_STDSTAT)) && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 &&
         p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 && (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     if (Cout_pad % 128 == 0) {
@@ -335,7 +341,8 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         }
         // SPADE convs run 32-channel chunks: their LDS image is then conflict-free at three workgroups per CU (conv_halo_kernel.h, halo_pad)
         static const bool spade32 = [] { const char* s = getenv("CANONSWAP_SPADE_CK32"); return !s || atoi(s) != 0; }();
-        const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !(spade32 && c.mode == MODE_SPADE)) ? 64 : 32;
+        const bool spade_ck32 = spade32 && c.mode == MODE_SPADE && !(spade256() && c.p.Cout_pad % 256 == 0);
+        const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !spade_ck32) ? 64 : 32;
         c.p.xcd_map = xcd_map_default();
         {   // cross-workgroup split-K when the launch cannot fill the chip (single-frame latency: the deep hourglass levels run 8-64
             // workgroups that each stream megabytes of weights): plain bias + activation + one output only
