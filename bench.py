@@ -8,10 +8,19 @@ rank 0 inside it.  Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), so the command has the same shape at every N.
+
+--streams S (BASELINE configs[4]): S concurrent videos, stream s on the rank group parallel.stream_groups() gives it
+(8 GPUs, 4 streams: GPU pair {2s, 2s+1}), one identity per stream, per-stream gather over a sub-communicator;
+reports per-stream and aggregate frames/s.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,9 +30,15 @@ if ROOT not in sys.path:
 
 ALGO_GFLOP_PER_FRAME = 2374.3      # 2*MAC of every conv on the primary path, as the reference runs it
 PEAK_TFLOPS_F16 = 2500.0           # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+WARP_BYTES_PER_FRAME = 2 * 17.56e6 + 4.19e6      # two fp32 feature warps (8.39 MB in + 0.79 MB grid + 8.39 MB out) + one fp16 copy
 
 
-def main():
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -33,19 +48,35 @@ def main():
                     help="fixed-size job (BASELINE configs[3]: --frames 1200): one step = one pass over a video of this many frames, "
                          "sharded over the ranks in contiguous blocks (strong scaling). Default 0: every rank runs --batch frames "
                          "per step (weak scaling)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="BASELINE configs[4]: this many concurrent videos, each with its own identity, placed by "
+                         "parallel.stream_groups (4 streams on 8 GPUs: stream s on GPU pair {2s, 2s+1})")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fixed-job", action="store_true", help="skip the fixed-size job reported next to the weak-scaling figure")
     ap.add_argument("--fp8-weights", action="store_true",
                     help="BASELINE configs[4] numerics: conv weights quantised to e4m3 with per-out-channel scales (expanded to f16 for "
                          "the MFMA, whose operands must share a format class); activations f16")
     ap.add_argument("--latency-mode", action="store_true",
                     help="BASELINE configs[1] (--batch 1): cross-workgroup split-K for the launches that cannot fill the chip")
     ap.add_argument("--identities", type=int, default=1,
-                    help="configs[4]: this many source identities resident at once, frames of a launch cycling through them")
-    ap.add_argument("--dump-crc", default="", help="rank 0 writes the CRC32 of every gathered frame of the last step here (tests)")
+                    help="this many source identities resident at once, frame g of the job using identity g mod n")
+    ap.add_argument("--dump-crc", default="", help="the leader of stream s writes the CRC32 of every gathered frame of the last step "
+                                                   "to this path (stream 0) / path.s<s> (tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: dry run of the multi-rank flow with all ranks sharing GPU 0 and host-side collectives (test only)")
-    a = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # same command shape as N = 1: spawn one rank per GPU under torch.distributed.run and hand its exit code back
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from canonswap_amd import parallel, synth
@@ -55,7 +86,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs a {a.gpus}-rank launch (WORLD_SIZE={world}); use torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     share_gpu = a.backend == "gloo"
     if share_gpu:
         local_rank = 0
@@ -68,46 +99,83 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(dev)}"]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, devices[0])
+        devices = got
 
     B, K, Wm = a.batch, a.steps, a.warmup
-    strong = a.frames > 0
-    n_total = a.frames if strong else B * world                 # frames per step over all ranks
-    f0, f1 = parallel.shard_range(n_total, rank, world)         # this rank's contiguous block of every step
-    n_local = f1 - f0
+    S = max(1, a.streams)
+    groups = parallel.stream_groups(world, S)               # rank list per stream
+    mine = parallel.streams_of_rank(groups, rank)           # [(stream, position in its group, identity slot here)]
+    k = len(mine)
+    if k < 1 or B % k:
+        raise SystemExit(f"--batch {B} must be a multiple of the {k} streams a rank hosts")
+    comms = [None] * S if (world == 1 or S == 1) else parallel.make_stream_comms(groups)      # S == 1: the default group
     sds = synth.to_torch(synth.make_state_dicts(0))                     # random-init weights of the real architecture
     sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), state_dicts=sds, max_batch=B,
                      fp8_weights=a.fp8_weights, latency_mode=a.latency_mode)
     eng = sw.engine
 
     # one-time broadcast of the source identities (2 KB each); every rank derives T's modulated weights locally
-    nid = max(1, min(a.identities, 8))
+    nid = S if a.streams else max(1, min(a.identities, 8))
     sid = torch.from_numpy(synth.make_identity(7, n=nid)).to(cdev) if rank == 0 else torch.zeros(nid, 512, device=cdev)
     parallel.broadcast_identity(sid, src=0)
     sid = sid.to(dev)
-    for k in range(nid):
-        eng.set_identity(sid[k:k + 1], slot=k)
-    frame_ids = sid[torch.arange(B, device=dev) % nid] if nid > 1 else None      # per-frame identity rows of one launch
+    if a.streams:
+        for s, _, slot in mine:                              # one identity slot per hosted stream
+            eng.set_identity(sid[s:s + 1], slot=slot)
+    else:
+        for j in range(nid):
+            eng.set_identity(sid[j:j + 1], slot=j)
 
-    # synthetic inputs resident in HBM: a pool of 4 x B distinct frames.  Frame g of a step (global index) reads pool frame
-    # (g + 131 * step) mod 4B, so the result of a frame does not depend on how many ranks share the job.
+    # synthetic inputs resident in HBM: a pool of 4 x B distinct frames.  Frame f of stream s reads pool frame (f + 17 s + 131 step) mod 4B
+    # at every step, so the result of a frame does not depend on how many ranks share the job.
     P = 4 * B
     inp = synth.make_frame_inputs(P, seed=1000, size=256)
-    pool = {k: torch.from_numpy(inp[k]).to(dev) for k in ("img", "x_t", "x_can")}
-    out_u8 = torch.empty(max(n_local, 1), 512, 512, 3, dtype=torch.uint8, device=dev)
+    pool = {key: torch.from_numpy(inp[key]).to(dev) for key in ("img", "x_t", "x_can")}
 
-    def step(i, gather=None):
-        """One step: this rank's block of the job in chunks of B frames; finished chunks go to rank 0 asynchronously."""
-        for t0 in range(0, n_local, B):
-            n = min(B, n_local - t0)
-            idx = (torch.arange(f0 + t0, f0 + t0 + n, device=dev) + 131 * i) % P
-            eng.swap_frames(pool["img"][idx], pool["x_t"][idx], pool["x_can"][idx], None if frame_ids is None else frame_ids[:n],
-                            want_f32=False, want_u8=True, out_u8=out_u8[t0:t0 + n])
+    class Plan:
+        """Frames of one step on this rank: for every local frame its stream, its index inside the stream's video and its identity slot."""
+        def __init__(self, per_stream):
+            self.per_stream = per_stream                     # frames per stream and step
+            spans = []
+            for s, q, slot in mine:
+                f0, f1 = parallel.shard_range(per_stream, q, len(groups[s]))
+                spans.append((s, slot, f0, f1))
+            self.span0 = spans[0][2:]
+            n_each = [f1 - f0 for _, _, f0, f1 in spans]
+            self.n_local = sum(n_each)
+            st, fr, sl = [], [], []
+            for j in range(max(n_each) if n_each else 0):    # hosted streams interleaved frame by frame
+                for (s, slot, f0, f1) in spans:
+                    if f0 + j < f1:
+                        st.append(s); fr.append(f0 + j)
+                        sl.append(slot if a.streams else (f0 + j) % nid)
+            self.slots = sl
+            self.base = (torch.tensor(fr, dtype=torch.long) + 17 * torch.tensor(st, dtype=torch.long)).to(dev)
+            self.chunks = [(t0, min(B, self.n_local - t0)) for t0 in range(0, self.n_local, B)]
+
+    weak = a.frames <= 0
+    plan = Plan((B // k) * len(groups[0]) if weak else a.frames)
+    fixed_T = 0 if (a.frames > 0 or a.streams or a.no_fixed_job) else (1200 if world > 1 else 300)      # configs[3] / configs[2]
+    fplan = Plan(fixed_T) if fixed_T else None
+    out_u8 = torch.empty(max(plan.n_local, fplan.n_local if fplan else 0, 1), 512, 512, 3, dtype=torch.uint8, device=dev)
+    gather_on = world > 1 and k == 1 and len(groups[mine[0][0]]) > 1
+    my_comm = comms[mine[0][0]]
+
+    def step(pl, i, gather=None, out_f32=None):
+        """One step: this rank's frames in chunks of B; finished chunks go to the stream's leader asynchronously."""
+        for t0, n in pl.chunks:
+            idx = (pl.base[t0:t0 + n] + 131 * i) % P
+            eng.swap_frames(pool["img"][idx], pool["x_t"][idx], pool["x_can"][idx], None, want_f32=False, want_u8=True,
+                            out_u8=out_u8[t0:t0 + n], out_f32=out_f32 if t0 == 0 else None, slots=pl.slots[t0:t0 + n])
+            out_f32 = None
             if gather is not None:
                 gather.push(out_u8[t0:t0 + n].to(cdev))
         return gather.finish() if gather is not None else None
-
-    for i in range(Wm):
-        step(i)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -115,85 +183,140 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    sync()
-    t0 = time.perf_counter()
-    gathered = None
-    for i in range(K):
-        g = parallel.ChunkedFrameGather(n_total, B, device=cdev) if world > 1 else None     # chunked gather over xGMI, overlapped
-        r = step(i, g)
-        gathered = r if world > 1 else out_u8[:n_local]
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        assert gathered.shape[0] == n_total
-        if a.dump_crc:
-            import zlib
-            fr = gathered.cpu().numpy()
-            with open(a.dump_crc, "w") as f:
-                json.dump([zlib.crc32(fr[k].tobytes()) for k in range(fr.shape[0])], f)
+    def timed(pl, steps):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides; returns (max-over-ranks seconds, per-rank seconds, frames on
+        the stream leader)."""
+        sync()
+        t0 = time.perf_counter()
+        gathered = None
+        for i in range(steps):
+            g = parallel.ChunkedFrameGather(pl.per_stream, B, device=cdev, group=my_comm) if gather_on else None
+            r = step(pl, i, g)
+            gathered = r if gather_on else out_u8[:pl.n_local]
+        sync()
+        dt = time.perf_counter() - t0
+        per_rank = [dt]
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [float(x.item()) for x in allt]
+        return max(per_rank), per_rank, gathered
 
-    # ---- roofline of the dominant kernel family (conv_igemm): HIP events around every launch, same workload
+    for i in range(Wm):
+        step(plan, i)
+    dt, per_rank, gathered = timed(plan, K)
+    if a.dump_crc:                                            # tests: CRC32 of every frame of the last step, per stream, on its leader
+        import zlib
+        for h, (s, q, _) in enumerate(mine):
+            if k == 1:
+                fr = gathered if q == 0 else None            # the group's first rank holds the gathered stream
+            else:
+                fr = out_u8[h:plan.n_local:k]                # hosted streams are interleaved frame by frame
+            if fr is None:
+                continue
+            fr = fr.cpu().numpy()
+            assert fr.shape[0] == plan.per_stream, (fr.shape, plan.per_stream)
+            crcs = [zlib.crc32(fr[j].tobytes()) for j in range(fr.shape[0])]
+            for path in ([a.dump_crc] if s == 0 else []) + [f"{a.dump_crc}.s{s}"]:
+                with open(path, "w") as f:
+                    json.dump(crcs, f)
+
+    fixed = None
+    if fplan is not None:
+        step(fplan, 0)                                       # warm-up pass (allocator, ragged last chunk)
+        fdt, _, fg = timed(fplan, 1)
+        if rank == 0:
+            assert fg.shape[0] == fixed_T
+            fixed = {"workload": f"BASELINE configs[{3 if world > 1 else 2}]: one 512x512 video of {fixed_T} frames, " +
+                                 (f"sharded over {world} GPUs in contiguous blocks, uint8 frames gathered to rank 0" if world > 1 else "batched on 1 GPU"),
+                     "frames": fixed_T, "seconds": round(fdt, 4), "value": round(fixed_T / fdt, 3), "unit": "frames/s", "scaling": "strong"}
+
+    # ---- roofline of the dominant kernel family (conv_halo_kernel): HIP events around every launch, same workload
     prof = None
     if rank == 0:
         eng.profile_begin()
         for i in range(K):
-            step(i)
+            step(plan, i)
         prof = eng.profile_end()
     if world > 1:
         dist.barrier()
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import canonswap_ref as O          # cpu_baseline leg: the oracle timed on this node's host cores
         cores = min(os.cpu_count() or 1, 32)           # threads used ("cores"); more than 32 slows PyTorch-CPU down on this path
         torch.set_num_threads(cores)
-        inp = synth.make_frame_inputs(1, seed=1000, size=256)
-        cargs = [torch.from_numpy(inp[k]) for k in ("img", "x_t", "x_can")]
-        cid = torch.from_numpy(synth.make_identity(7))
-        O.swap_frame(sds, *cargs, cid)                 # warm-up frame
-        n_cpu, t1 = 8, time.perf_counter()          # about 11 s of CPU work
+        # parity of THIS binary in THIS run: first and last frame of the first launch (step 0) against the fp32 oracle
+        from canonswap_amd import pack
+        t0, n = plan.chunks[0]
+        o32 = torch.empty(n, 3, 512, 512, dtype=torch.float32, device=dev)
+        idx = plan.base[:n] % P                            # step 0, first launch
+        eng.swap_frames(pool["img"][idx], pool["x_t"][idx], pool["x_can"][idx], None, want_f32=True, want_u8=True,
+                        out_u8=out_u8[:n], out_f32=o32, slots=plan.slots[:n])
+        torch.cuda.synchronize(dev)
+        idx, ids_cpu = idx.cpu(), sid.cpu()
+        osd = synth.to_torch(pack.quantize_conv_weights_e4m3(sds)) if a.fp8_weights else sds      # what the engine was given
+        worst, mad, cargs, cid = 1e9, 0.0, None, None
+        for j in sorted({0, n - 1}):
+            cargs = [torch.from_numpy(inp[key][int(idx[j]):int(idx[j]) + 1]) for key in ("img", "x_t", "x_can")]
+            row = mine[j % k][0] if a.streams else plan.slots[j]
+            cid = ids_cpu[row:row + 1]
+            with torch.no_grad():
+                ref = O.swap_frame(osd, *cargs, cid)["out"]
+            worst = min(worst, O.psnr(o32[j:j + 1].cpu(), ref))
+            d = out_u8[j:j + 1].cpu().numpy().astype(np.float64) - O.parse_output(ref).astype(np.float64)
+            mad = max(mad, float(np.abs(d).mean()))
+        parity = {"psnr_db_min": round(worst, 2), "u8_mean_abs_diff": round(mad, 4),
+                  "parity_sample": f"frames 0 and {n - 1} of the first {n}-frame launch vs the fp32 CPU oracle" +
+                                   (" running the same e4m3-quantised weights" if a.fp8_weights else "")}
+        n_cpu, t1 = 8, time.perf_counter()             # about 11 s of CPU work (the two parity frames above were the warm-up)
         for _ in range(n_cpu):
-            O.swap_frame(sds, *cargs, cid)
+            O.swap_frame(osd, *cargs, cid)
         cdt = time.perf_counter() - t1
         cpu = {"value": round(n_cpu / cdt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
-               "sample": f"{n_cpu} frames (1 warm-up), batch 1, fp32 PyTorch-CPU restatement of the same path (oracle/)"}
+               "sample": f"{n_cpu} frames (2 warm-up), batch 1, fp32 PyTorch-CPU restatement of the same path (oracle/)"}
 
-    traffic, traffic_src = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    traffic, traffic_src, warp_traffic = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if rank == 0 and os.path.exists(tpath):      # PMC counters cannot be read from inside this process: committed rocprofv3 passes
-        import json as _json
-        t = _json.load(open(tpath))
+        t = json.load(open(tpath))
         if int(t.get("batch", -1)) == B:
             traffic = t["fetch_bytes_per_conv_launch_x2"] + t["write_bytes_per_conv_launch_raw"]
             traffic_src = "profiles/hbm_traffic.json: " + t["source"]
+            if "warp_fetch_bytes_per_launch_x2" in t:
+                warp_traffic = t["warp_fetch_bytes_per_launch_x2"] + t["warp_write_bytes_per_launch_raw"]
 
     if rank == 0:
-        frames = K * n_total
+        frames = K * plan.per_stream * S
         fps = frames / dt
         conv_s = prof["conv_ms"] / 1e3
         achieved = prof["conv_flops"] / conv_s / 1e12
+        if a.streams:
+            wl = (f"BASELINE configs[4]: {S} concurrent 512x512 video streams, stream s on ranks {groups[0] if S == 1 else '/'.join(str(g) for g in groups)}, "
+                  "one identity per stream")
+        elif weak:
+            wl = (f"BASELINE configs[2]: 512x512 video, {B} frames batched per launch on each GPU, steady state over {frames} frames "
+                  f"({K} launches per GPU)")
+        else:
+            wl = f"BASELINE configs[3]: 512x512 video of {plan.per_stream} frames sharded over {world} GPU(s) in contiguous blocks"
         line = {
             "metric": "frames/sec at 512x512 (generator hot path F->W->T->R->W->G)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f16 activations x e4m3 weights (per-out-channel scale, expanded to f16 for the MFMA)" if a.fp8_weights else "f16",
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[3]: 512x512 video of {n_total} frames sharded over {world} GPU(s) in contiguous "
-                                    "blocks" if strong else "BASELINE configs[2]: 512x512 video, frames batched on each GPU") +
-                                   " (256x256 crops in, random-init weights of the real architecture)",
-                       "frames_per_step": n_total, "frames_per_launch_per_gpu": B, "frames_total": frames,
-                       "parallelism": f"frame-shard x{world}", "identities_resident": nid, "latency_mode": bool(a.latency_mode),
-                       "accumulate": "fp32", "debug_decodes": False},
+            "ranks_seen": ranks_seen, "devices": devices,
+            "config": {"workload": wl + " (256x256 crops in, random-init weights of the real architecture)",
+                       "frames_per_step": plan.per_stream * S, "frames_per_launch_per_gpu": B, "frames_total": frames,
+                       "parallelism": f"frame-shard x{world}" + (f", {S} streams" if a.streams else ""), "identities_resident": nid,
+                       "latency_mode": bool(a.latency_mode), "accumulate": "fp32", "debug_decodes": False},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_unit": "HBM bytes per conv launch",
                          "traffic_source": traffic_src,
-                         "kernel": "conv_halo + conv_igemm (every convolution launch)", "launches_per_step": prof["conv_launches"] // K,
+                         "kernel": "conv_halo_kernel / vol32_kernel (every convolution launch of the step)", "launches_per_step": prof["conv_launches"] // K,
                          "avg_launch_us": round(prof["conv_ms"] * 1e3 / prof["conv_launches"], 2),
-                         "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * n_local) / 1e9, 1),
+                         "algorithmic_gflop_per_frame": round(prof["conv_flops"] / (K * plan.n_local) / 1e9, 1),
                          # MFMA work actually issued (padded channel counts, phase-decomposed up-sampling convs): the utilisation of the
                          # matrix pipe, as opposed to the algorithmic rate above (ADVICE r1)
                          "executed_tflops": round(prof["exec_flops"] / conv_s / 1e12, 2),
@@ -204,12 +327,23 @@ def main():
             # the HBM-bound row of the path: trilinear feature warp (F.grid_sample, warping_network.py:46-47), fp32 volumes:
             # algorithmic bytes per frame and call = 8.39 MB in + 0.79 MB grid + 8.39 MB out (+ 4.19 MB fp16 copy on the first call)
             "warp_roofline": {"bound": "hbm", "kernel": "grid_sample_kernel",
-                              "achieved": round((2 * 17.56e6 + 4.19e6) * n_local * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
+                              "achieved": round(WARP_BYTES_PER_FRAME * plan.n_local * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s",
-                              "frac": round((2 * 17.56e6 + 4.19e6) * n_local * K / (prof["warp_ms"] / 1e3) / 8e12, 4),
-                              "avg_launch_us": round(prof["warp_ms"] * 1e3 / max(prof["warp_launches"], 1), 2), "traffic": None},
+                              "frac": round(WARP_BYTES_PER_FRAME * plan.n_local * K / (prof["warp_ms"] / 1e3) / 8e12, 4),
+                              "avg_launch_us": round(prof["warp_ms"] * 1e3 / max(prof["warp_launches"], 1), 2), "traffic": warp_traffic,
+                              "traffic_unit": "HBM bytes per warp launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)"},
             "cpu_baseline": cpu,
         }
+        if parity:
+            line.update(parity)
+        if fixed:
+            line["fixed_job"] = fixed
+        if a.streams:
+            per = []
+            for s, g in enumerate(groups):
+                ts = max(per_rank[r] for r in g)
+                per.append({"stream": s, "ranks": g, "frames": K * plan.per_stream, "value": round(K * plan.per_stream / ts, 3), "unit": "frames/s"})
+            line["streams"] = per
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

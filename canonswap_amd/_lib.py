@@ -11,7 +11,10 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_halo.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
+# test-only cross-check kernel (the first-generation implicit-GEMM conv): its own library, never linked into the product
+TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "csrc", "test_igemm.hip")
+TEST_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcanonswap_test.so")
 HEADERS = [os.path.join(CSRC, f) for f in ("common.h", "conv_epilogue.h", "conv_halo_kernel.h")] + \
           [os.path.join(os.path.dirname(HERE), "include", "canonswap_hip.h")]
 HALO_NGROUPS = 8          # conv_halo.hip is compiled once per -DHALO_GROUP=k (slices of its instantiation table)
@@ -76,11 +79,92 @@ def build(force: bool = False, lib_path: str | None = None, extra_flags=(), obj_
     return lib_path
 
 
+def build_test_lib(force: bool = False) -> str:
+    """tests/libcanonswap_test.so = tests/csrc/test_igemm.hip (+ conv_igemm.hip): used by tests/hip_ops.py only."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = [TEST_SRC, os.path.join(os.path.dirname(TEST_SRC), "conv_igemm.hip")] + HEADERS
+    if force or not os.path.exists(TEST_LIB_PATH) or os.path.getmtime(TEST_LIB_PATH) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run([hipcc, *HIPCC_FLAGS, "-shared", "-Wl,-Bsymbolic", TEST_SRC, "-o", TEST_LIB_PATH], check=True)
+    return TEST_LIB_PATH
+
+
+_test_lib = None
+
+
+def load_test_lib():
+    global _test_lib
+    if _test_lib is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise RuntimeError(f"{TEST_LIB_PATH} is missing: run __graft_entry__.build()")
+        lib = C.CDLL(TEST_LIB_PATH)
+        lib.cs_test_last_error.restype = C.c_char_p
+        lib.cs_test_conv_igemm.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
+        _test_lib = lib
+    return _test_lib
+
+
 def toolchain() -> str:
     """hipcc version string (recorded by build(): the dynamic-shape conv kernels rely on hand-counted waits, see conv_halo_kernel.h)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
     return " | ".join(l.strip() for l in out.splitlines() if "version" in l.lower())[:200]
+
+
+def isa_check(obj_dir: str | None = None) -> dict:
+    """Compile-time guard for the hand-counted weight ring of the dynamic-shape conv kernels (conv_halo_kernel.h, ST = 0).
+
+    Those kernels stream weight fragments with inline-asm `global_load_dwordx4` the compiler does not track and wait for them with
+    an explicit `s_waitcnt vmcnt(WCH * (PFD - 1))`.  A compiler change that moves, duplicates or drops one of these would read stale
+    registers without any diagnostic.  This disassembles every conv_halo object and checks, per
+    ST = 0 kernel: exactly PFD = 4 counted waits `s_waitcnt vmcnt(3 * WCH)`; after each of them an MFMA that reads the ring slot's
+    registers and then that slot's reload (WCH `global_load_dwordx4` into the same registers the prologue primed it with); and the
+    final `s_waitcnt vmcnt(0)` drain before the epilogue.  Raises RuntimeError on any mismatch; returns {kernel: waits found}."""
+    import re
+    obj_dir = obj_dir or OBJ_DIR
+    objdump = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not os.path.exists(objdump):
+        raise RuntimeError(f"isa_check: {objdump} not found")
+    seen = {}
+    for g in range(HALO_NGROUPS):
+        obj = os.path.join(obj_dir, f"conv_halo_g{g}.o")
+        subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True)
+        co = obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950"
+        try:
+            txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        finally:
+            for f in os.listdir(obj_dir):
+                if f.startswith(f"conv_halo_g{g}.o.0."):
+                    os.remove(os.path.join(obj_dir, f))
+        for m in re.finditer(r"^[0-9a-f]+ <(_Z16conv_halo_kernelILi\d+ELi\d+ELi(\d+)ELi\d+ELi\d+ELi\d+ELb[01]ELb[01]ELi0EEv10ConvParams)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)",
+                             txt, re.S | re.M):
+            name, wch, body = m.group(1), int(m.group(2)), m.group(3).split("\n")
+            want = f"s_waitcnt vmcnt({3 * wch})"
+            waits = [i for i, l in enumerate(body) if l.strip().startswith(want) and "lgkmcnt" not in l]
+            if len(waits) != 4:
+                raise RuntimeError(f"isa_check: {name}: {len(waits)} x `{want}` in the K loop, expected 4 (one per ring slot)")
+            loads = [(i, re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", l)) for i, l in enumerate(body)]
+            loads = [(i, int(q.group(1))) for i, q in loads if q]
+            prime = [r for i, r in loads if i < waits[0]][-4 * wch:]          # the ring as the prologue primed it: 4 slots x WCH fragments
+            if len(prime) != 4 * wch:
+                raise RuntimeError(f"isa_check: {name}: the prologue primes {len(prime)} ring registers, expected {4 * wch}")
+            for k, w in enumerate(waits):
+                slot = prime[k * wch:(k + 1) * wch]
+                end = waits[k + 1] if k + 1 < 4 else len(body)
+                seg = body[w:end]
+                rel = [i for i, r in loads if w < i < end and r in slot]
+                if len(rel) < wch:
+                    raise RuntimeError(f"isa_check: {name}: ring slot {k} is not reloaded into v{slot} after its wait")
+                first_reload = min(rel) - w
+                uses = [j for j, l in enumerate(seg[:first_reload]) if "v_mfma" in l and any(f"v[{r}:{r + 3}]" in l for r in slot)]
+                if not uses:
+                    raise RuntimeError(f"isa_check: {name}: no MFMA reads ring slot {k} (v{slot}) between its wait and its reload")
+            tail = "\n".join(body[waits[-1]:])
+            if "s_waitcnt vmcnt(0)" not in tail:
+                raise RuntimeError(f"isa_check: {name}: the ring is not drained (s_waitcnt vmcnt(0)) before the epilogue")
+            seen[name] = len(waits)
+    if not seen:
+        raise RuntimeError("isa_check: no dynamic-shape conv_halo kernel found in the objects (name mangling changed?)")
+    return seen
 
 
 class ConvDesc(C.Structure):

@@ -11,7 +11,7 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };   // GELU: exact erf form (nn.GELU default)
 enum { MODE_STD = 0, MODE_TBLEND = 1, MODE_SPADE = 2, MODE_PIXSHUF = 3,
        MODE_STDSTAT = 4 };   // MODE_STD + per-tile channel statistics of the stored output (selected by the launchers when p.stat_out)
-// tile configurations of conv_igemm (pixels x channels per 256-thread workgroup)
+// tile configurations of the test-only cross-check kernel tests/csrc/conv_igemm.hip (pixels x channels per 256-thread workgroup)
 enum { CFG_128x128 = 0, CFG_128x64 = 1, CFG_256x32 = 2, CFG_256x16 = 3 };
 // tile configurations of conv_halo
 enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 13, CFG_H_128x16 = 14, CFG_H_256x16 = 15,
@@ -114,8 +114,8 @@ struct ConvParams {
 
 void cs_set_error(const char* fmt, ...);
 
-// ---- kernel launchers (conv_igemm.hip, kernels.hip); all asynchronous on `st`
-int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);
+// ---- kernel launchers (conv_halo.hip, kernels.hip); all asynchronous on `st`
+int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);   // tests/csrc/conv_igemm.hip: test-only library
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st);
 const half_t* cs_zero_page();   // per-process device buffer of zeros (lazily allocated on the current device)
 

@@ -1,4 +1,4 @@
-// Shared epilogue of the gfx950 conv kernels (conv_igemm.hip, conv_halo.hip).
+// Shared epilogue of the gfx950 conv kernels (conv_halo.hip, vol32.hip; also the test-only tests/csrc/conv_igemm.hip).
 // Accumulator layout (v_mfma_f32_16x16x32_f16 with weights as the A operand): acc[ci][pi][r] is
 // channel (16-block ci, row l4*4 + r) of position (16-block pi, column l15).
 #pragma once
@@ -43,6 +43,10 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
 // ReLU / LeakyReLU / identity as ONE branch-free formula: slope 0 / s / 1 (bit-identical to the switch above for those three).
 // The epilogue is fully unrolled; a runtime switch per element (with the erf polynomial of GELU inlined each time) made it 18 000
 // instructions and ~1 800 branches long, fetch-bound at 13-38 % of a wave's lifetime (profiles/r02_timeline_*.txt).
+// NaN: fminf / fmaxf return the non-NaN operand, so a NaN accumulator (inf - inf after an fp16 overflow upstream) is stored as 0 by
+// this formula instead of propagating.  Kept: `v > 0 ? v : v * slope` would propagate NaN but turns relu(-inf) into
+// -inf * 0 = NaN, and the two-instruction forms cost an issue slot more in a VALU-issue-bound epilogue.  Overflow is watched where it
+// would start: CANONSWAP_AMAX=1 reports the largest |value| every conv stored in fp16 (inf shows up there).
 __device__ __forceinline__ float lin_act(float v, float slope) { return fmaf(slope, fminf(v, 0.f), fmaxf(v, 0.f)); }
 __device__ __forceinline__ float lin_slope(int act, float slope) { return act == ACT_NONE ? 1.f : (act == ACT_LRELU ? slope : 0.f); }
 

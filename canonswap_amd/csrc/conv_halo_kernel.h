@@ -1,6 +1,6 @@
 // Convolution with LDS-staged input patches for gfx950 (CDNA4).
 //
-// Same GEMM view, packed-weight format and epilogues as conv_igemm.hip, different data movement:
+// GEMM view: M = positions, N = Cout, K = taps x Cin; packed weights [kstep][Cout_pad][32]; data movement:
 //   * activations: the (tile + kernel-1) input "halo" box of a CK-channel chunk is staged ONCE in LDS and every
 //     tap of the kernel reads its shifted window from there -- 9x (3x3), 27x (3x3x3) or 343x (7x7x7) fewer
 //     global/L2 reads, address computations and bounds checks than gathering a tile per tap;

@@ -244,14 +244,6 @@ void set_tile(ConvParams& p, int BM, int prefW, int prefH)
     p.nTW = p.W / tw; p.nTH = p.H / th; p.nTD = p.D / tdd; p.nTN = (p.N + tn - 1) / tn;
 }
 
-int pick_cfg(int Cout_pad)
-{
-    if (Cout_pad % 128 == 0) return CFG_128x128;
-    if (Cout_pad % 64 == 0) return CFG_128x64;
-    if (Cout_pad % 32 == 0) return CFG_256x32;
-    return CFG_256x16;
-}
-
 // tile configuration of the 32->32 3x3x3 convs on the [H][W][D][C] volumes: 256 positions (4x4x16) x 32 channels; 128-position
 // tiles measured slower (more halo re-reads than the extra occupancy returns)
 int cfg_v32() { return CFG_H_256x32; }
@@ -271,12 +263,6 @@ int xcd_map_default()
 {
     static const int v = [] { const char* s = getenv("CANONSWAP_XCD_MAP"); return s ? atoi(s) : 2; }();   // 2: +0.8 % on the step (r02 A/B)
     return v;
-}
-
-bool halo_enabled()
-{
-    static const bool on = getenv("CANONSWAP_NO_HALO") == nullptr;
-    return on;
 }
 
 int pick_halo_cfg(const ConvParams& p, int mode)
@@ -313,8 +299,7 @@ int pick_halo_cfg(const ConvParams& p, int mode)
 
 int amax_after(cs_engine* e, const struct ConvCall& c, hipStream_t st);
 
-// Launch one convolution. Default path: conv_halo (LDS-staged input patch, register-streamed weights);
-// conv_igemm handles the depth-collapsing occlusion conv (and everything when CANONSWAP_NO_HALO is set).
+// Launch one convolution on conv_halo (LDS-staged input patch, register-streamed weights).
 int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
 {
     const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
@@ -328,7 +313,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         }
         e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps;
     }
-    if (halo_enabled() && c.p.inD == c.p.D) {
+    if (c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
         const bool is3d = c.p.KD > 1;
@@ -374,12 +359,8 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         TRY(e->run(0, st, [&] { return launch_conv_halo(c.p, hcfg, ck, c.mode, st); }, c.name, fl));
         return amax_after(e, c, st);
     }
-    if (c.cfg < 0) c.cfg = pick_cfg(c.p.Cout_pad);
-    const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
-    if (!prefW) { prefW = 16; prefH = BM / 16; }
-    set_tile(c.p, BM, prefW, prefH);
-    c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (c.cfg == CFG_128x128 ? 2 : 4);
-    return e->run(0, st, [&] { return launch_conv(c.p, c.cfg, c.mode, st); }, c.name, fl);
+    cs_set_error("%s: no conv_halo launch for this convolution (depth-collapsing convs are not supported)", c.name);
+    return -1;
 }
 
 float* stats_slot(cs_engine* e);
@@ -543,15 +524,10 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     ConvCall oc = mk(e->w_occ, e->dm_pred, td(nullptr, (long)FD * 4096 * 144, 0, 64L * 144, 144), B, 1, 64, 64);
     oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
     oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 16); oc.p.out0_f32 = 1;
-    if (halo_enabled()) {
-        // 7 real output channels, 560 K-steps: the four waves split the K-steps (0.27 -> 0.20 ms at B = 16); in latency mode the
-        // K-steps are split over workgroups instead (32 tiles cannot fill the chip)
-        oc.hcfg = e->latency_mode ? CFG_H_128x32 : CFG_H_SK128x32;
-        TRY(go(e, oc, st));
-    } else {
-        cs_set_error("the occlusion conv needs conv_halo (grouped input channels)");
-        return -1;
-    }
+    // 7 real output channels, 560 K-steps: the four waves split the K-steps (0.27 -> 0.20 ms at B = 16); in latency mode the
+    // K-steps are split over workgroups instead (32 tiles cannot fill the chip)
+    oc.hcfg = e->latency_mode ? CFG_H_128x32 : CFG_H_SK128x32;
+    TRY(go(e, oc, st));
     TRY(e->run(1, st, [&] { return launch_occ_finish(e->dm_occpart, e->occ_b, e->dm_occ, B, 64, 64, st); }, "occ_finish"));
     return 0;
 }
@@ -794,7 +770,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
         TRY(go(e, c1, st));
     }
     ConvCall ci = mk(e->g_img, e->g_o256, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
-    ci.mode = MODE_PIXSHUF; ci.cfg = CFG_256x16;
+    ci.mode = MODE_PIXSHUF;
     ci.p.Cout = 16;
     ci.p.act0 = ACT_SIGMOID;
     ci.p.out0 = td(img, 0, 0, 0, 0); ci.p.out0_f32 = 1;
@@ -1131,14 +1107,16 @@ extern "C" int cs_set_identity(cs_engine* e, int slot, const float* id, void* st
     const size_t fused_elems = (size_t)(512 / 32) * 9 * 1024 * 32;       // packed [kstep][1024 rows][32]
     for (int i = 0; i < 14; ++i) {
         TLayer& L = e->t_l[i];
-        if (!L.wset[slot]) {     // first use of this slot: own copy of the fused buffer (the shared W rows never change)
+        if (!L.wset[slot]) {     // first use of this slot: own buffer for the fused [W; w_mod] rows
             half_t* w = nullptr;
             TRY(e->alloc(&w, fused_elems));
-            TRY(copy_dd(w, L.wset[0], fused_elems * sizeof(half_t), st));
             L.wset[slot] = w;
             const long ofs = w - L.wset[0];
             CS_CHECK_HIP(hipMemcpy(L.wofs + slot, &ofs, sizeof(long), hipMemcpyHostToDevice));
         }
+        // the shared W rows come from slot 0's blob: copied on the slot's first use AND after every cs_finalize_weights (a new
+        // checkpoint clears slot_set; an old copy would pair the previous W rows with the new w_mod rows - ADVICE r2)
+        if (slot != 0 && !e->slot_set[slot]) TRY(copy_dd(L.wset[slot], L.wset[0], fused_elems * sizeof(half_t), st));
         TRY(e->run(1, st, [&] { return launch_t_style(id, L.fc, e->style + i * 512, 1, st); }, "t_style"));
         TRY(e->run(1, st, [&] { return launch_t_modulate(L.raw, e->style + i * 512, L.wset[slot], i, st); }, "t_modulate"));
     }
@@ -1450,10 +1428,8 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
         p.ragged = d->ragged;
         return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);
     }
-    c.cfg = d->cfg >= 0 ? d->cfg : pick_cfg(p.Cout_pad);
-    const int BM = (c.cfg == CFG_128x128 || c.cfg == CFG_128x64) ? 128 : 256;
-    set_tile(p, BM, d->tile_w ? d->tile_w : 16, d->tile_h ? d->tile_h : BM / 16);
-    return launch_conv(p, c.cfg, c.mode, (hipStream_t)stream);
+    cs_set_error("cs_op_conv: cfg %d is not a conv_halo configuration (the conv_igemm cross-check kernel lives in the test-only library)", d->cfg);
+    return -1;
 }
 
 extern "C" int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream)

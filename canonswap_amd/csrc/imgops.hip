@@ -47,7 +47,9 @@ __global__ void __launch_bounds__(256) se_conv_kernel(const float* __restrict__ 
     out[(long)n * H * W + (long)y * W + x] = take_min ? fminf(c, acc) : acc;
 }
 
-// max over the pixels below the threshold, per sample (crop.py:45); two deterministic stages (max is order independent)
+// max over the pixels below the threshold (crop.py:45: `x[~mask].max()` runs over the WHOLE (N,1,H,W) tensor, not per sample -
+// ADVICE r2); two deterministic stages (max is order independent): per-(sample, block) partials, then every thread of the final
+// pass reduces all N x nparts of them
 __global__ void __launch_bounds__(256) se_max_kernel(const float* __restrict__ x, long P, float thr, float* __restrict__ part)
 {
     const int n = blockIdx.y;
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(256) se_final_kernel(float* __restrict__ x, lo
 {
     const int n = blockIdx.y;
     float m = -INFINITY;
-    for (int i = 0; i < nparts; ++i) m = fmaxf(m, part[n * nparts + i]);
+    for (int i = 0; i < nparts; ++i) m = fmaxf(m, part[i]);          // nparts = blocks x samples: the maximum over the whole batch
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float v = x[(long)n * P + i];
@@ -96,7 +98,7 @@ int launch_soft_erosion(const float* mask, float* tmp_a, float* tmp_b, const flo
     const int nparts = 64;
     hipLaunchKernelGGL(se_max_kernel, dim3(nparts, B), dim3(256), 0, st, soft, P, thr, part);
     LAUNCH_CHECK("se_max");
-    hipLaunchKernelGGL(se_final_kernel, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, st, soft, P, thr, part, nparts, hard);
+    hipLaunchKernelGGL(se_final_kernel, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, st, soft, P, thr, part, nparts * B, hard);
     LAUNCH_CHECK("se_final");
     return 0;
 }

@@ -250,12 +250,19 @@ class Engine:
         return out
 
     def swap_frames(self, img, x_t, x_can, source_id=None, want_f32=True, want_u8=False, debug=False,
-                    out_f32=None, out_u8=None):
-        """Whole loop body of can_swap_pipeline_e2e.py:242-263 for B frames, on device."""
+                    out_f32=None, out_u8=None, slots=None):
+        """Whole loop body of can_swap_pipeline_e2e.py:242-263 for B frames, on device.
+        slots: identity slot per frame (ints, set with set_identity) instead of `source_id` rows - no identity lookup at all
+        (multi-stream callers that placed their identities themselves)."""
         img = self._in(img, (3, 256, 256)); x_t = self._in(x_t, (21, 3)); x_can = self._in(x_can, (21, 3))
         self._same_batch(img, x_t, x_can)
         B = img.shape[0]
-        slots = self.identity_slots(source_id, B) if source_id is not None else self._default_slots(B)
+        if slots is not None:
+            slots = [int(k) for k in slots]
+            if len(slots) != B or source_id is not None:
+                raise ValueError("slots: one identity slot per frame, and no source_id")
+        else:
+            slots = self.identity_slots(source_id, B) if source_id is not None else self._default_slots(B)
         out_f32 = self._out(out_f32, (B, 3, 512, 512), torch.float32) if (want_f32 or out_f32 is not None) else None
         out_u8 = self._out(out_u8, (B, 512, 512, 3), torch.uint8) if (want_u8 or out_u8 is not None) else None
         rec = self._new(B, 3, 512, 512) if debug else None

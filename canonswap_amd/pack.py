@@ -3,7 +3,7 @@
 Replaces ``can_swapper.load_cpk`` (src/can_swap_e2e.py:87-100): the same six state-dicts (same key names)
 are ingested; eval-mode BatchNorm and the legacy spectral-norm parametrisation are folded into the
 convolution weights, channels are reordered for the engine's channels-last layouts, and every
-convolution is packed into the K-step order of ``conv_igemm`` (csrc/conv_igemm.hip):
+convolution is packed into the K-step order of the conv kernels (csrc/conv_halo_kernel.h):
 
     packed[kstep][row][kk] (fp16),  kstep = ((chunk*KD + kd)*KH + kh)*KW + kw,  in-channel = chunk*32 + kk
 

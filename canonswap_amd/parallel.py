@@ -19,11 +19,47 @@ def shard_range(n_frames: int, rank: int, world: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def broadcast_identity(source_id: torch.Tensor, src: int = 0) -> torch.Tensor:
-    """One-time broadcast of the 512-float identity embedding from rank `src` (in place)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(source_id, src=src)
+def broadcast_identity(source_id: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    """One-time broadcast of the 512-float identity embedding from (global) rank `src` (in place), over `group` if given."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(source_id, src=src, group=group)
     return source_id
+
+
+def stream_groups(world: int, n_streams: int):
+    """BASELINE configs[4] placement: `n_streams` concurrent videos on `world` ranks.
+
+    world >= n_streams: stream s owns the contiguous ranks {s*g, ..., s*g + g - 1}, g = world / n_streams (8 GPUs, 4 streams:
+    stream s -> GPU pair {2s, 2s+1}); its frames shard over those ranks, its identity lives in identity slot 0 of each of them and
+    its frames are gathered to the first rank of the group over a per-stream sub-communicator.
+    world < n_streams: every rank hosts n_streams / world whole streams (stream s on rank s mod world), one identity slot per hosted
+    stream, frames of the hosted streams interleaved in one launch (the per-sample modulated convolution of
+    adaptive_modulate.py:157-167).
+    Returns a list of rank lists, one per stream."""
+    if world < 1 or n_streams < 1:
+        raise ValueError("world and n_streams must be positive")
+    if world >= n_streams:
+        if world % n_streams:
+            raise ValueError(f"{world} ranks do not split evenly over {n_streams} streams")
+        g = world // n_streams
+        return [list(range(s * g, (s + 1) * g)) for s in range(n_streams)]
+    if n_streams % world:
+        raise ValueError(f"{n_streams} streams do not split evenly over {world} ranks")
+    return [[s % world] for s in range(n_streams)]
+
+
+def streams_of_rank(groups, rank: int):
+    """[(stream, position of `rank` inside the stream's group, identity slot on this rank)] for every stream `rank` serves."""
+    mine = [s for s, g in enumerate(groups) if rank in g]
+    return [(s, groups[s].index(rank), k) for k, s in enumerate(mine)]
+
+
+def make_stream_comms(groups):
+    """One sub-communicator per multi-rank stream (every rank must call this with the same `groups`: dist.new_group is
+    collective over the default group).  Entry s is None for single-rank streams or without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [None] * len(groups)
+    return [dist.new_group(ranks=g) if len(g) > 1 else None for g in groups]
 
 
 def gather_frames(local: torch.Tensor, n_frames: int, dst: int = 0):
@@ -53,11 +89,14 @@ class ChunkedFrameGather:
     n_frames: total frames of the job, sharded by shard_range(); chunk: frames per collective.
     """
 
-    def __init__(self, n_frames: int, chunk: int, frame_shape=(512, 512, 3), device="cpu", dst: int = 0):
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.world = dist.get_world_size() if self.on else 1
-        self.rank = dist.get_rank() if self.on else 0
+    def __init__(self, n_frames: int, chunk: int, frame_shape=(512, 512, 3), device="cpu", dst: int = 0, group=None):
+        """group: sub-communicator of one stream (stream_groups / make_stream_comms); `dst` is then the rank INSIDE the group."""
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
         self.dst, self.chunk, self.n_frames = dst, chunk, n_frames
+        self.dst_global = dist.get_global_rank(group, dst) if (self.on and group is not None) else dst
         self.counts = [shard_range(n_frames, r, self.world) for r in range(self.world)]
         self.n_local = self.counts[self.rank][1] - self.counts[self.rank][0]
         nmax = max(b - a for a, b in self.counts)
@@ -82,7 +121,7 @@ class ChunkedFrameGather:
             pad = torch.zeros((self.chunk,) + self.frame_shape, dtype=torch.uint8, device=self.device)
             pad[: frames.shape[0]] = frames
         pieces = [self.buf[r, c * self.chunk:(c + 1) * self.chunk] for r in range(self.world)] if self.rank == self.dst else None
-        self.works.append((dist.gather(pad.contiguous(), pieces, dst=self.dst, async_op=True), pad))
+        self.works.append((dist.gather(pad.contiguous(), pieces, dst=self.dst_global, group=self.group, async_op=True), pad))
 
     def finish(self):
         """Wait for every chunk (ranks that ran out of frames push empty chunks first). Frames in order on dst, else None."""

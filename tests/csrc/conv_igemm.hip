@@ -1,3 +1,4 @@
+// TEST-ONLY cross-check kernel (built into libcanonswap_test.so, never into the product library).
 // Implicit-GEMM convolution for gfx950 (CDNA4): fp16 operands, fp32 accumulate on
 // v_mfma_f32_16x16x32_f16, channels-last activations with arbitrary position strides.
 //
@@ -14,8 +15,8 @@
 //        that the ds_read_b128 lane groups of the MFMA operand fetch are bank-conflict free
 //   MFMA operand roles are swapped (A = weights -> rows = channels, B = activations -> columns =
 //   positions) so each lane ends up with 4 consecutive channels of one position: 8/16-byte stores.
-#include "common.h"
-#include "conv_epilogue.h"
+#include "../../canonswap_amd/csrc/common.h"
+#include "../../canonswap_amd/csrc/conv_epilogue.h"
 
 __device__ __forceinline__ int swz_slot(int row, int seg)
 {

@@ -59,6 +59,11 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
     d.xcd_map = 0 if xcd_map is None else xcd_map + 1
     d.ragged = int(ragged)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if -1 <= cfg <= 3:        # the independently written cross-check kernel (tests/csrc/conv_igemm.hip, test-only library)
+        tl = _lib.load_test_lib()
+        if tl.cs_test_conv_igemm(C.byref(d), st) != 0:
+            raise RuntimeError("cs_test_conv_igemm failed: " + tl.cs_test_last_error().decode(errors="replace"))
+        return
     _lib.check(lib.cs_op_conv(C.byref(d), st), "cs_op_conv")
 
 

@@ -104,3 +104,29 @@ def test_300_frame_loop_properties(swapper):
     # frames 96.. repeat the pool (same inputs, other batch slot / ragged batch): identical bytes
     assert torch.equal(u8a[0:32], u8a[96:128])
     assert torch.equal(u8a[288:300], u8a[0:12])
+
+
+def test_min_psnr_over_32_frames_two_identities(swapper, state_dicts, batch):
+    """the worst frame, not a sample of frames.  32 distinct frames x 2 identities (alternating inside ONE B = 32
+    launch, i.e. the per-sample modulated convolution of adaptive_modulate.py:157-167) against the fp32 CPU oracle of
+    can_swap_pipeline_e2e.py:242-267; asserts the MINIMUM float PSNR >= 50 dB, and on the uint8 frames (parse_output truncation,
+    can_swap_e2e.py:314-322) PSNR >= 48 dB with a mean |diff| below 0.6 LSB.  About 32 oracle frames of CPU work."""
+    from canonswap_amd import synth
+    from oracle import canonswap_ref as O
+    args, _ = batch
+    ids = torch.from_numpy(synth.make_identity(7, n=2))
+    rows = ids[torch.arange(B) % 2]
+    r = swapper.swap_frames(args["img"].cuda(), args["x_t"].cuda(), args["x_can"].cuda(), rows.cuda(), want_u8=True)
+    got, got8 = r["out"].cpu(), r["out_u8"].cpu().numpy()
+    worst, worst8, mad = 1e9, 1e9, 0.0
+    for i in range(B):
+        with torch.no_grad():
+            ref = O.swap_frame(state_dicts, args["img"][i:i + 1], args["x_t"][i:i + 1], args["x_can"][i:i + 1], rows[i:i + 1])["out"]
+        worst = min(worst, O.psnr(got[i:i + 1], ref))
+        ref8 = O.parse_output(ref).astype(np.float64)
+        d = got8[i:i + 1].astype(np.float64) - ref8
+        worst8 = min(worst8, 10.0 * np.log10(255.0 ** 2 / max(float((d ** 2).mean()), 1e-12)))
+        mad = max(mad, float(np.abs(d).mean()))
+    print(f"min PSNR over {B} frames x 2 identities: float {worst:.2f} dB, uint8 {worst8:.2f} dB, worst mean |diff| {mad:.3f} LSB")
+    assert worst >= PSNR_GATE, worst
+    assert worst8 >= 48.0 and mad < 0.6, (worst8, mad)

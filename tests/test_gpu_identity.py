@@ -115,3 +115,27 @@ def test_output_buffers_are_validated(swapper):
         swapper.engine.swap_frames(*args, sid, out_f32=torch.empty(1, 3, 512, 512, dtype=torch.float16, device="cuda"))
     with pytest.raises(ValueError):
         swapper.engine.swap_frames(*args, sid, out_u8=torch.empty(2, 512, 512, 3, dtype=torch.uint8, device="cuda")[:, :, :, :])
+
+
+def test_reloading_weights_refreshes_every_identity_slot(state_dicts_np, feats):
+    """after a second load_state_dicts on a live engine, identity slots >= 1 must pair the NEW shared W rows with
+    the new modulated rows (they keep their own copy of the fused [W; w_mod] buffer).  Load A, use two identities, load B,
+    compare with an engine that only ever saw B - bit for bit."""
+    from canonswap_amd import synth
+    from canonswap_amd.can_swap_e2e import can_swapper
+    sd_a = synth.to_torch(state_dicts_np)
+    sd_b = synth.to_torch(synth.make_state_dicts(1))
+    ids = _ids(7, 8)
+    f = feats[:2].cuda()
+    live = can_swapper(None, state_dicts=sd_a, max_batch=2)
+    out_a = live.swap_module(f, ids.cuda()).clone()                   # slots 0 and 1 now hold checkpoint A
+    live.load_state_dicts(sd_b)
+    got = live.swap_module(f, ids.cuda()).clone()
+    fresh = can_swapper(None, state_dicts=sd_b, max_batch=2)
+    want = fresh.swap_module(f, ids.cuda())
+    assert not torch.equal(out_a, want)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the reverse order of first use after the reload (slot 1 resolved before slot 0)
+    live.load_state_dicts(sd_a)
+    back = live.swap_module(f.flip(0).contiguous(), ids.flip(0).contiguous().cuda())
+    assert torch.equal(back[1], out_a[0]) and torch.equal(back[0], out_a[1])

@@ -19,15 +19,33 @@ def test_soft_erosion_vs_reference_vectors(swapper, golden):
         se = swapper.soft_mask(ks, thr, it)
         # built on this host with the reference's formula: the fp32 sum that normalises it may differ in the last bit between CPUs
         assert np.allclose(se.weight.cpu().numpy(), g[name + "_weight"], rtol=1e-6, atol=0)
-        x = torch.from_numpy(np.stack([g[f"{name}_0_in"], g[f"{name}_1_in"]]).astype(np.int32))[:, None]
-        soft, hard = se(x)
-        soft, hard = soft.cpu().numpy()[:, 0], hard.cpu().numpy()[:, 0]
-        for k in (0, 1):
+        for k in (0, 1):          # the vectors were made one sample per call, as the pipeline calls it (the max of crop.py:45 is over the call's tensor)
+            x = torch.from_numpy(g[f"{name}_{k}_in"].astype(np.int32))[None, None]
+            soft, hard = se(x)
+            soft, hard = {k: soft.cpu().numpy()[0, 0]}, {k: hard.cpu().numpy()[0, 0]}
             flips = hard[k] != g[f"{name}_{k}_hard"]
             d = np.abs(soft[k] - g[f"{name}_{k}_soft"])[~flips]
             print(name, k, "hard-mask flips", int(flips.sum()), "max |soft diff| elsewhere", float(d.max()))
             assert flips.sum() <= 4, (name, k, int(flips.sum()))          # pixels whose conv value sits within rounding of 0.9
             assert d.max() < 2e-6, (name, k, float(d.max()))
+
+
+def test_soft_erosion_batch_normalises_by_the_max_of_the_whole_batch(swapper, golden):
+    """`x[~mask] /= x[~mask].max()` (crop.py:45) takes the maximum over the whole (N,1,H,W) tensor.  A batch of two
+    different masks against the oracle (pinned to the reference class for N = 1, same code for N = 2)."""
+    from oracle import cv_ref as R
+    g = golden("soft_erosion.npz")
+    x = torch.from_numpy(np.stack([g["e2e_0_in"], (g["e2e_1_in"] * 0.5)]).astype(np.float32))[:, None]
+    se = swapper.soft_mask(21, 0.9, 3)
+    soft, hard = se(x)
+    want, wmask = R.soft_erosion(x, 21, 0.9, 3)
+    flips = hard.cpu().numpy().astype(bool) != wmask.numpy()
+    assert flips.sum() <= 8
+    d = np.abs(soft.cpu().numpy() - want.numpy())[~flips]
+    assert d.max() < 2e-6, float(d.max())
+    # ... and it differs from normalising each sample by its own maximum
+    own, _ = R.soft_erosion(x[1:2], 21, 0.9, 3)
+    assert float((own - want[1:2]).abs().max()) > 1e-3
 
 
 def test_prepare_crops_bit_exact(swapper):

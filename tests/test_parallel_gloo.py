@@ -96,3 +96,62 @@ def test_chunked_gather_single_process_is_a_no_op():
     g = parallel.ChunkedFrameGather(5, 2, frame_shape=(2, 2, 3))
     g.push(torch.zeros(2, 2, 2, 3, dtype=torch.uint8))
     assert g.finish() is None
+
+
+def test_stream_groups_placement():
+    """stream s -> GPU pair {2s, 2s+1} (8 GPUs, 4 streams); fewer ranks than streams: whole streams per rank."""
+    assert parallel.stream_groups(8, 4) == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert parallel.stream_groups(4, 2) == [[0, 1], [2, 3]]
+    assert parallel.stream_groups(8, 1) == [list(range(8))]
+    assert parallel.stream_groups(2, 4) == [[0], [1], [0], [1]]
+    assert parallel.streams_of_rank(parallel.stream_groups(8, 4), 5) == [(2, 1, 0)]
+    assert parallel.streams_of_rank(parallel.stream_groups(2, 4), 1) == [(1, 0, 0), (3, 0, 1)]
+    for bad in ((6, 4), (3, 2), (2, 3)):
+        try:
+            parallel.stream_groups(*bad)
+        except ValueError:
+            continue
+        raise AssertionError(bad)
+
+
+def _stream_worker(rank, world, port, n_streams, per_stream, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        groups = parallel.stream_groups(world, n_streams)
+        comms = parallel.make_stream_comms(groups)              # collective: every rank creates every sub-communicator
+        ids = torch.stack([torch.full((512,), float(s + 1)) for s in range(n_streams)]) if rank == 0 else torch.zeros(n_streams, 512)
+        parallel.broadcast_identity(ids, src=0)                 # one broadcast of every stream's identity over the default group
+        (s, pos, slot), = parallel.streams_of_rank(groups, rank)
+        assert slot == 0
+        tag = int(ids[s, 0].item())                             # stand-in for the engine: frame value = 10 * frame index + identity tag
+        a, b = parallel.shard_range(per_stream, pos, len(groups[s]))
+        g = parallel.ChunkedFrameGather(per_stream, chunk, frame_shape=(2, 2, 3), group=comms[s], dst=0)
+        for t0 in range(a, b, chunk):
+            n = min(chunk, b - t0)
+            g.push(torch.stack([torch.full((2, 2, 3), (10 * i + tag) % 256, dtype=torch.uint8) for i in range(t0, t0 + n)]))
+        out = g.finish()
+        if pos == 0:
+            q.put((s, rank, out[:, 0, 0, 0].tolist()))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_streams_on_four_ranks_gather_per_stream():
+    """configs[4] shape at world 4: stream s on ranks {2s, 2s+1}; each stream's frames arrive on ITS leader (ranks 0 and 2), in frame
+    order, carrying that stream's identity; the two gathers run on separate sub-communicators."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, n_streams, per_stream, port = 4, 2, 7, _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, n_streams, per_stream, 2, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(n_streams))
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert [(s, r) for s, r, _ in got] == [(0, 0), (1, 2)]
+    for s, _, frames in got:
+        assert frames == [(10 * i + s + 1) % 256 for i in range(per_stream)]
