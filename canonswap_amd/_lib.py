@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "vol32.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
 # test-only cross-check kernel (the first-generation implicit-GEMM conv): its own library, never linked into the product
 TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "csrc", "test_igemm.hip")
 TEST_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcanonswap_test.so")
@@ -185,6 +185,7 @@ class ConvDesc(C.Structure):
         ("out1", C.c_void_p), ("out1_sN", C.c_long), ("out1_sD", C.c_long), ("out1_sH", C.c_long), ("out1_sW", C.c_long),
         ("stats", C.c_void_p),
         ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int), ("xcd_map", C.c_int), ("ragged", C.c_int),
+        ("hilo", C.c_int), ("stat_out", C.c_void_p),
     ]
 
 

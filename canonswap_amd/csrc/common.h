@@ -18,7 +18,8 @@ enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 
        CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */, CFG_H_128x256 = 17,
        CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */,
        CFG_H_256x160 = 19 /* 2x2 waves of 128 positions x 80 channels, one workgroup per CU: half the weight bytes per MFMA of 128x160 */,
-       CFG_H_256x64 = 20 /* 2x2 waves of 128 positions x 32 channels (3x3x3, 8x8x4 tiles): the same for the 64-channel hourglass blocks */ };
+       CFG_H_256x64 = 20 /* 2x2 waves of 128 positions x 32 channels (3x3x3, 8x8x4 tiles): the same for the 64-channel hourglass blocks */,
+       CFG_VOL32 = 30 /* vol32.hip (cs_op_conv: force that kernel) */ };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {
@@ -117,6 +118,10 @@ void cs_set_error(const char* fmt, ...);
 // ---- kernel launchers (conv_halo.hip, kernels.hip); all asynchronous on `st`
 int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);   // tests/csrc/conv_igemm.hip: test-only library
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st);
+// vol32.hip: the 3x3x3 32 -> 32 convolutions on [N][H][W][16][32] volumes (weights in registers, persistent workgroups marching along H)
+bool vol32_supported(const ConvParams& p);
+int vol32_stat_nblk(const ConvParams& p);        // partial-statistics blocks per sample when ConvParams::stat_out is set
+int launch_vol32(const ConvParams& p, hipStream_t st);
 const half_t* cs_zero_page();   // per-process device buffer of zeros (lazily allocated on the current device)
 
 int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);

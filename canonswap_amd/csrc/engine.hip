@@ -313,6 +313,13 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         }
         e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps;
     }
+    // the 3x3x3 32 -> 32 convolutions of the feature volume run on their own kernel (vol32.hip; CANONSWAP_VOL32=0: A/B knob, conv_halo)
+    static const bool vol32_on = [] { const char* s = getenv("CANONSWAP_VOL32"); return !s || atoi(s) != 0; }();
+    if (vol32_on && vol32_supported(c.p)) {
+        c.stat_nblk = vol32_stat_nblk(c.p);
+        TRY(e->run(0, st, [&] { return launch_vol32(c.p, st); }, c.name, fl));
+        return amax_after(e, c, st);
+    }
     if (c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
@@ -1417,7 +1424,9 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     p.s2 = d->s2; p.t2 = d->t2; p.act1 = d->act1; p.slope1 = d->slope1;
     p.out1 = td(d->out1, d->out1_sN, d->out1_sD, d->out1_sH, d->out1_sW);
     p.stats = d->stats;
+    p.hilo = d->hilo; p.stat_out = d->stat_out;
     c.mode = d->mode;
+    if (d->cfg == CFG_VOL32) return launch_vol32(p, (hipStream_t)stream);
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo
         const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;

@@ -135,11 +135,13 @@ typedef struct cs_conv_desc {
     void* out1; long out1_sN, out1_sD, out1_sH, out1_sW;
     const float* stats;       /* SPADE: [N][C][2] = (mean, 1/sqrt(var+eps)) from cs_op_chan_stats */
     int mode;                 /* 0 std, 1 T blend, 2 SPADE, 3 pixel-shuffle + sigmoid */
-    int cfg;                  /* -1 auto conv_igemm, 0..3 conv_igemm tile cfg, -2 auto conv_halo, 10..18 conv_halo tile cfg */
+    int cfg;                  /* -2 auto conv_halo, 10..20 conv_halo tile cfg, 30 the vol32 kernel (3x3x3 32 -> 32 on [N][H][W][16][32]); -1, 0..3: test-only library */
     int tile_w, tile_h;       /* 0 = auto */
     int ck;                   /* conv_halo channel chunk: 0 auto, 32 or 64 */
     int xcd_map;              /* conv_halo workgroup -> tile mapping: 0 engine default, k > 0 forces mapping k - 1 (common.h) */
     int ragged;               /* Cin % 32 == 16 and wgt went through cs_op_pair_ragged: paired taps in the last chunk (cfg 19 / 20 only) */
+    int hilo;                 /* split-precision conv (util.py:528-544 convs of R): in = [hi | lo] per voxel, wgt = chunks W_hi | W_lo | W_hi, Cin = 96 */
+    float* stat_out;          /* optional per-block partial (sum, sum of squares) of the stored fp32 out0 (cfg 30: [N][ceil(H/8) * W/2][32][2]) */
 } cs_conv_desc;
 int cs_op_conv(const cs_conv_desc* d, void* stream);
 /* in place: re-pack the last 32-channel chunk of a packed conv weight [chunks * taps][Cout_pad][32] (Cin % 32 == 16) so that two

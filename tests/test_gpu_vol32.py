@@ -1,0 +1,174 @@
+"""vol32.hip (the 3x3x3 32 -> 32 convolutions of the feature volume: ResBlock3d util.py:80-102, ResBlock3D_stage3_leak util.py:528-544)
+against (a) plain PyTorch fp32 CPU conv3d of the fp16-rounded operands and (b) the generic LDS-halo kernel it replaces.
+
+Both kernels accumulate the 27 taps of an output element in the same (kd, kh, kw) order, one 32-channel MFMA step each, and apply the
+same epilogue formulas in the same order, so (b) is bit-exact: torch.equal.  Shapes cover a whole 64 x 64 volume with an odd batch,
+segments cut along H (a batch too small to fill the chip with whole strips), rows fewer than the ring, and W = 8 (one strip, both
+halo columns outside)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+CFG_VOL32, CFG_H_256x32 = 30, 12
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _randn(r, *shape, scale=1.0):
+    return torch.from_numpy((scale * r.standard_normal(shape)).astype(np.float32))
+
+
+def _hwdc(t):                # N C D H W -> N H W D C
+    return t.permute(0, 3, 4, 2, 1).contiguous()
+
+
+def _view(t):                # N H W D C storage -> logical [N, D, H, W, C] view
+    return t.permute(0, 3, 1, 2, 4)
+
+
+def _back(t):                # N H W D C -> N C D H W fp32 cpu
+    return t.float().cpu().permute(0, 4, 3, 1, 2)
+
+
+def _run(cfg, x16, wp, b, res, s2, t2, first):
+    """first: conv1 of a ResBlock3d (fp16 output, ReLU); else conv2 (fp32 residual stream in / out + pre-activated fp16 copy)."""
+    import hip_ops as ops
+    N, H, W, D, Cc = x16.shape
+    kw = dict(tile=(4, 4)) if cfg == CFG_H_256x32 else {}
+    if first:
+        out = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float16, device=DEV)
+        ops.conv(_view(x16), wp, 32, 32, (3, 3, 3), bias=b, act0="relu", out0=_view(out), cfg=cfg, **kw)
+        torch.cuda.synchronize()
+        return out, None
+    out0 = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float32, device=DEV)
+    out1 = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float16, device=DEV)
+    ops.conv(_view(x16), wp, 32, 32, (3, 3, 3), bias=b, res=_view(res), out0=_view(out0), s2=s2, t2=t2, act1="relu", out1=_view(out1),
+             cfg=cfg, **kw)
+    torch.cuda.synchronize()
+    return out0, out1
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 64, 64), (1, 64, 64), (2, 24, 16), (5, 2, 8), (1, 1, 8), (2, 9, 24), (32, 64, 64), (2, 7, 8)])
+@pytest.mark.parametrize("first", [True, False])
+def test_vol32_equals_halo_kernel_and_torch(N, H, W, first):
+    import hip_ops as ops
+    r = _rng(1000 * N + 10 * H + W + int(first))
+    Cc, D = 32, 16
+    x = _randn(r, N, Cc, D, H, W)
+    x = torch.relu(x) if first else x                         # conv1 sees post-ReLU activations, conv2 any sign
+    res = _randn(r, N, Cc, D, H, W)
+    w = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04)
+    b = _randn(r, Cc, scale=0.1)
+    s2 = torch.from_numpy(r.uniform(0.5, 1.5, Cc).astype(np.float32)); t2 = _randn(r, Cc, scale=0.2)
+    x16 = _hwdc(x).half().to(DEV)
+    resd = _hwdc(res).to(DEV)
+    wp = ops.packed_weight(w, 32, DEV)
+    args = (x16, wp, b.to(DEV), resd, s2.to(DEV), t2.to(DEV), first)
+    new0, new1 = _run(CFG_VOL32, *args)
+    halo_ok = H % min(H, 4) == 0 and W % 4 == 0                # the halo kernel tiles H x W in 4 x 4 (vol32 takes any H)
+    old0, old1 = _run(CFG_H_256x32, *args) if halo_ok else (None, None)
+    y = F.conv3d(x.half().float(), w.half().float(), b, padding=1)
+    if first:
+        assert ops.rel_err(_back(new0), F.relu(y)) < 2e-3
+    else:
+        y = y + res
+        assert ops.rel_err(_back(new0), y) < 2e-3
+        assert ops.rel_err(_back(new1), F.relu(y * s2.view(1, -1, 1, 1, 1) + t2.view(1, -1, 1, 1, 1))) < 3e-3
+        assert not halo_ok or torch.equal(new1, old1)
+    assert not halo_ok or torch.equal(new0, old0), float((new0.float() - old0.float()).abs().max())
+
+
+def test_vol32_strided_views_and_untouched_neighbours():
+    """Output into every other sample of a larger buffer and input from a sample-strided view: the kernel honours the N / H / W strides
+    (a column of 16 voxels x 32 channels stays contiguous) and writes nothing else."""
+    import hip_ops as ops
+    r = _rng(77)
+    N, H, W, D, Cc = 2, 16, 16, 16, 32
+    x = _randn(r, N, Cc, D, H, W)
+    w = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04)
+    b = _randn(r, Cc, scale=0.1)
+    big_in = torch.zeros(2 * N, H, W, D, Cc, dtype=torch.float16, device=DEV)
+    big_in[1::2] = _hwdc(x).half().to(DEV)
+    big_in[0::2] = 9.0
+    big_out = torch.full((2 * N, H, W, D, Cc), -7.0, dtype=torch.float16, device=DEV)
+    wp = ops.packed_weight(w, 32, DEV)
+    ops.conv(_view(big_in[1::2]), wp, 32, 32, (3, 3, 3), bias=b.to(DEV), act0="relu", out0=_view(big_out[0::2]), cfg=CFG_VOL32)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv3d(x.half().float(), w.half().float(), b, padding=1))
+    assert ops.rel_err(_back(big_out[0::2]), ref) < 2e-3
+    assert bool((big_out[1::2] == -7.0).all())
+
+
+def test_engine_resblocks_use_vol32_and_match_halo_path(state_dicts, monkeypatch):
+    """The appearance feature extractor (12 of these convolutions) through the engine with the kernel on (default) and off
+    (CANONSWAP_VOL32=0 is read once per process, so the second engine runs in a subprocess): identical bits."""
+    import os
+    import subprocess
+    import sys
+    from canonswap_amd import synth
+    from canonswap_amd.can_swap_e2e import can_swapper
+    inp = synth.make_frame_inputs(2, seed=31, size=256)
+    img = torch.from_numpy(inp["img"])
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=2)
+    got = sw.extract_feature_3d(img.cuda()).cpu()
+    code = ("import torch, sys; sys.path.insert(0, %r); from canonswap_amd import synth; from canonswap_amd.can_swap_e2e import can_swapper;"
+            "sd = synth.to_torch(synth.make_state_dicts(0)); sw = can_swapper(None, state_dicts=sd, max_batch=2);"
+            "img = torch.from_numpy(synth.make_frame_inputs(2, seed=31, size=256)['img']);"
+            "torch.save(sw.extract_feature_3d(img.cuda()).cpu(), sys.argv[1])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = "/tmp/vol32_off.pt"
+    env = dict(os.environ, CANONSWAP_VOL32="0")
+    r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = torch.load(path)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (1, 16, 8), (3, 24, 16)])
+def test_vol32_split_precision_with_statistics(N, H, W):
+    """The split-precision form of R's GroupNorm convolutions (util.py:528-544; ConvParams::hilo): activations [hi | lo], weights
+    [W_hi | W_lo | W_hi], out = W_hi x_hi + W_lo x_hi + W_hi x_lo accumulated in that order - bit-identical to the halo kernel - and
+    good to ~1e-6 against an fp64 convolution of the UNROUNDED operands (what the split buys).  Partial statistics: per (column pair,
+    8 rows) sums that must add up to the sums of the stored output."""
+    import hip_ops as ops
+    r = _rng(5000 + N + H + W)
+    Cc, D = 32, 16
+    x = _randn(r, N, Cc, D, H, W)
+    w = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04)
+    b = _randn(r, Cc, scale=0.1)
+    xh = _hwdc(x)
+    hi = xh.half()
+    lo = (xh - hi.float()).half()
+    x2 = torch.cat([hi, lo], dim=-1).contiguous().to(DEV)                       # [N][H][W][D][64]
+    whi = w.half().float()
+    wlo = (w - whi).half().float()
+    wp = ops.packed_weight(torch.cat([whi, wlo, whi], dim=1), 32, DEV)            # Cin = 96: three 32-channel chunks
+    outs = {}
+    for cfg in (CFG_VOL32, CFG_H_256x32):
+        out = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float32, device=DEV)
+        kw = dict(tile=(4, 4)) if cfg == CFG_H_256x32 else {}
+        nblk = ((H + 7) // 8) * (W // 2)
+        part = torch.zeros(N, nblk, Cc, 2, dtype=torch.float32, device=DEV) if cfg == CFG_VOL32 else None
+        ops.conv(_view(x2), wp, 32, 32, (3, 3, 3), cin=96, bias=b.to(DEV), out0=_view(out), cfg=cfg, hilo=True, stat_out=part, **kw)
+        torch.cuda.synchronize()
+        outs[cfg] = (out, part)
+    new, part = outs[CFG_VOL32]
+    old, _ = outs[CFG_H_256x32]
+    assert torch.equal(new, old), float((new - old).abs().max())
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    assert ops.rel_err(_back(new).double(), ref) < 3e-6
+    # statistics: block (h // 8, w // 2) of sample n holds sum / sum of squares over its 2 columns x 8 rows x 16 depth slices
+    o = new.double().cpu()                                                       # [N][H][W][D][C]
+    Hb = (H + 7) // 8
+    want = torch.zeros(N, Hb, W // 2, Cc, 2, dtype=torch.float64)
+    for hb in range(Hb):
+        blk = o[:, hb * 8:(hb + 1) * 8].reshape(N, -1, W // 2, 2, D, Cc)
+        want[:, hb, :, :, 0] = blk.sum(dim=(1, 3, 4))
+        want[:, hb, :, :, 1] = (blk ** 2).sum(dim=(1, 3, 4))
+    got = part.double().cpu().view(N, Hb, W // 2, Cc, 2)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-5
