@@ -186,6 +186,8 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p),
         ("mode", C.c_int), ("cfg", C.c_int), ("tile_w", C.c_int), ("tile_h", C.c_int), ("ck", C.c_int), ("xcd_map", C.c_int), ("ragged", C.c_int),
         ("hilo", C.c_int), ("stat_out", C.c_void_p),
+        ("xf_kind", C.c_int), ("xf_y", C.c_void_p), ("xf_res", C.c_void_p), ("xf_out", C.c_void_p),
+        ("xf_stats", C.c_void_p), ("xf_gamma", C.c_void_p), ("xf_beta", C.c_void_p), ("xf_slope", C.c_float),
     ]
 
 

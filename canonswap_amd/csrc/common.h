@@ -97,12 +97,35 @@ struct ConvParams {
     // tiles (halo overlaps of neighbouring tiles hit in that XCD's L2).  2: flat grid, contiguous range per XCD with the channel
     // blocks of one tile adjacent (the input tile is fetched into the L2 once for all of them).
     int xcd_map;
+    // vol32 only - transform staging (xf_kind != 0): the conv's input is not read from `in` but computed while it is staged, from fp32
+    // volumes [N][H][W][16][32] (strides of xf_y / xf_res / xf_out: sN, sH, sW; a column is contiguous):
+    //   kind 1: a = xf_y                                                      (replaces the stand-alone split16 pass)
+    //   kind 2: a = lrelu((xf_y - mean) * rstd * gamma + beta [+ xf_res])      (GroupNorm(32,32) apply of util.py:531-540 fused into the consumer conv;
+    //           mean / rstd per (sample, channel) from xf_stats [N][32][2]; with xf_out the interior of a is also written back: the new
+    //           residual stream)
+    // and split into [hi | lo] fp16 on the way into LDS (the conv must be a split-precision one: hilo).
+    int xf_kind;
+    TDesc xf_y, xf_res, xf_out;
+    const float* xf_stats; const float* xf_gamma; const float* xf_beta;
+    float xf_slope;
 #ifdef CS_TIMELINE
     // instrumented builds only (tools/timeline.py): per-wave s_memtime stamps of the kernel's phases, 12 x u64 per wave
     unsigned long long* tl;
     long tl_cap;            // capacity in waves
 #endif
 };
+
+// GroupNorm apply + residual + LeakyReLU as ONE fixed sequence of operations (explicit fma: no contraction choices), shared by
+// norm_act_kernel (kernels.hip) and the transform staging of vol32.hip so that both give the same bits:
+//   sc = rstd * gamma, sh = beta - mean * sc, a = v * sc + sh + res, lrelu
+__device__ __forceinline__ float gn_scale(float rstd, float gamma) { return rstd * gamma; }
+__device__ __forceinline__ float gn_shift(float mean, float sc, float beta) { return fmaf(-mean, sc, beta); }
+__device__ __forceinline__ float gn_lrelu(float v, float sc, float sh, float rr, float slope)
+{
+    float a = fmaf(v, sc, sh);
+    a = a + rr;
+    return a > 0.f ? a : a * slope;
+}
 
 #define CS_CHECK_HIP(expr)                                                                  \
     do {                                                                                    \

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <string>
 #include <vector>
@@ -299,6 +300,11 @@ int pick_halo_cfg(const ConvParams& p, int mode)
 
 int amax_after(cs_engine* e, const struct ConvCall& c, hipStream_t st);
 
+bool vol32_enabled() { static const bool on = [] { const char* s = getenv("CANONSWAP_VOL32"); return !s || atoi(s) != 0; }(); return on; }
+// GroupNorm apply / hi-lo split of R's stage-3 blocks inside the consumer conv's staging (vol32 transform staging) instead of stand-alone
+// norm_act / split16 passes (CANONSWAP_VOL32_XF=0: A/B knob)
+bool vol32_xf() { static const bool on = [] { const char* s = getenv("CANONSWAP_VOL32_XF"); return !s || atoi(s) != 0; }(); return on && vol32_enabled(); }
+
 // Launch one convolution on conv_halo (LDS-staged input patch, register-streamed weights).
 int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
 {
@@ -314,12 +320,12 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps;
     }
     // the 3x3x3 32 -> 32 convolutions of the feature volume run on their own kernel (vol32.hip; CANONSWAP_VOL32=0: A/B knob, conv_halo)
-    static const bool vol32_on = [] { const char* s = getenv("CANONSWAP_VOL32"); return !s || atoi(s) != 0; }();
-    if (vol32_on && vol32_supported(c.p)) {
+    if (vol32_enabled() && vol32_supported(c.p)) {
         c.stat_nblk = vol32_stat_nblk(c.p);
         TRY(e->run(0, st, [&] { return launch_vol32(c.p, st); }, c.name, fl));
         return amax_after(e, c, st);
     }
+    if (c.p.xf_kind) { cs_set_error("%s: transform staging needs the vol32 kernel", c.name); return -1; }
     if (c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
@@ -620,9 +626,57 @@ bool r_split()
 
 TDesc hwdc3_split(void* p) { return td(p, VOL * 2, 64, (long)FW * FD * 64, (long)FD * 64); }
 
+// Stage-3 blocks with the GroupNorm apply fused into the consumer convolution (vol32 transform staging, ConvParams::xf_*): per block
+//   conv1 reads  a0 = [block 0: x;  later: lrelu(gn2(y2') + x') of the previous block, written back as the new residual stream x]
+//   conv2 reads  a1 = lrelu(gn1(y1))
+// and one stand-alone norm_act closes the stage.  Five fp32-volume buffers rotate (vs[0..2] and the two split-precision buffers, which
+// this path does not use otherwise): a conv never writes a volume that it, or a neighbouring workgroup of the same launch, still reads.
+int run_stage3_xf(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
+{
+    float* pool[5] = {e->vs[0], e->vs[1], e->vs[2], (float*)e->vsp[0], (float*)e->vsp[1]};
+    auto pick = [&](std::initializer_list<const float*> busy) -> float* {
+        for (float* b : pool) { bool used = false; for (const float* u : busy) used |= (u == b); if (!used) return b; }
+        return nullptr;
+    };
+    float* X = e->vs[*cur];                 // residual stream
+    const float* pend_y = X; const float* pend_stats = nullptr; const float* pend_g = nullptr; const float* pend_b = nullptr;      // conv1's input
+    for (int i = 0; i < 3; ++i) {           // ResBlock3D_stage3_leak (util.py:528-544)
+        float* Xn = i ? pick({X, pend_y}) : X;                          // where the transformed input of conv1 goes (the new residual stream)
+        float* Y1 = pick({X, pend_y, Xn});
+        ConvCall c1 = mk(blk[i].c1sp, e->vsp[0], hwdc3_split(nullptr), B, FD, FH, FW);
+        c1.p.hilo = 1;
+        c1.p.xf_kind = i ? 2 : 1; c1.p.xf_y = hwdc3((void*)pend_y);
+        if (i) {
+            c1.p.xf_stats = pend_stats; c1.p.xf_gamma = pend_g; c1.p.xf_beta = pend_b; c1.p.xf_slope = 0.01f;
+            c1.p.xf_res = hwdc3(X); c1.p.xf_out = hwdc3(Xn);
+        }
+        c1.p.out0 = hwdc3(Y1); c1.p.out0_f32 = 1;
+        float* s1;
+        TRY(go_stats(e, c1, 32, VOX, &s1, st, 4, 4));
+        X = Xn;
+        float* Y2 = pick({X, Y1});
+        ConvCall c2 = mk(blk[i].c2sp, e->vsp[0], hwdc3_split(nullptr), B, FD, FH, FW);
+        c2.p.hilo = 1;
+        c2.p.xf_kind = 2; c2.p.xf_y = hwdc3(Y1); c2.p.xf_stats = s1; c2.p.xf_gamma = blk[i].g1; c2.p.xf_beta = blk[i].b1; c2.p.xf_slope = 0.01f;
+        c2.p.out0 = hwdc3(Y2); c2.p.out0_f32 = 1;
+        float* s2;
+        TRY(go_stats(e, c2, 32, VOX, &s2, st, 4, 4));
+        pend_y = Y2; pend_stats = s2; pend_g = blk[i].g2; pend_b = blk[i].b2;
+    }
+    // out = lrelu(gn2(y2) + x): the stage's result (fp32 stream + fp16 copy for what follows)
+    int nxt = 0;
+    while (e->vs[nxt] == X || e->vs[nxt] == pend_y) ++nxt;
+    TRY(e->run(1, st, [&] { return launch_norm_act(pend_y, pend_stats, pend_g, pend_b, X, 0.01f, e->vs[nxt], e->va[0], last_pre ? last_pre->s : nullptr,
+                                                   last_pre ? last_pre->t : nullptr, 512, last_pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st, 0); },
+                "norm_act"));
+    *cur = nxt;
+    return 0;
+}
+
 int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
 {
     const bool sp = r_split();
+    if (sp && vol32_xf()) return run_stage3_xf(e, blk, B, cur, last_pre, st);
     if (sp) TRY(e->run(1, st, [&] { return launch_split16(e->vs[*cur], e->vsp[0], (long)B * VOL, st); }, "split16"));
     for (int i = 0; i < 3; ++i) {   // ResBlock3D_stage3_leak (util.py:528-544)
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
@@ -1425,6 +1479,13 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     p.out1 = td(d->out1, d->out1_sN, d->out1_sD, d->out1_sH, d->out1_sW);
     p.stats = d->stats;
     p.hilo = d->hilo; p.stat_out = d->stat_out;
+    if (d->xf_kind) {       // transform staging (vol32): the fp32 source volumes share out0's strides
+        p.xf_kind = d->xf_kind;
+        p.xf_y = td((void*)d->xf_y, d->out0_sN, d->out0_sD, d->out0_sH, d->out0_sW);
+        p.xf_res = td((void*)d->xf_res, d->out0_sN, d->out0_sD, d->out0_sH, d->out0_sW);
+        p.xf_out = td((void*)d->xf_out, d->out0_sN, d->out0_sD, d->out0_sH, d->out0_sW);
+        p.xf_stats = d->xf_stats; p.xf_gamma = d->xf_gamma; p.xf_beta = d->xf_beta; p.xf_slope = d->xf_slope;
+    }
     c.mode = d->mode;
     if (d->cfg == CFG_VOL32) return launch_vol32(p, (hipStream_t)stream);
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo

@@ -495,8 +495,8 @@ __global__ void __launch_bounds__(256) norm_act_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float* st = stats + ((long)n * 32 + c + r) * 2;
-        float a = (v[r] - st[0]) * st[1] * gamma[c + r] + beta[c + r] + rr[r];
-        a = a > 0.f ? a : a * slope;
+        const float sc = gn_scale(st[1], gamma[c + r]);
+        float a = gn_lrelu(v[r], sc, gn_shift(st[0], sc, beta[c + r]), rr[r], slope);      // common.h: the same sequence as vol32's transform staging
         v[r] = a;
         if (s2) { const int j = (int)((i + r) % period2); a = a * s2[j] + t2[j]; }
         o16[r] = (half_t)act_f(a, act2, slope2);

@@ -72,6 +72,11 @@ struct Vol32Params {
     half_t* out1; int o1_sN, o1_sH, o1_sW;
     const float* s2; const float* t2;
     float* stat_out; int stat_nblk;          // [N][stat_nblk][32][2] partial (sum, sum of squares) of the stored out0 values
+    // transform staging (XF kernels; ConvParams::xf_*)
+    const float* xf_y; int xy_sN, xy_sH, xy_sW;
+    const float* xf_res; int xr_sN, xr_sH, xr_sW;
+    float* xf_out; int xo_sN, xo_sH, xo_sW;
+    const float* xf_stats; const float* xf_gamma; const float* xf_beta; float xf_slope;
     int nstrips, nseg, seg_rows, items;
 #ifdef V32_TL
     unsigned long long* tl; long tl_cap;     // 12 x u64 per wave: cycles in [startup, prologue wait, DMA issue, stores, main loop, epilogue, vm wait, barrier, tail], steps, hw id
@@ -94,9 +99,14 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // K-steps of an output element in exactly that order (= conv_halo_kernel's chunk order).  W_hi stays in registers; W_lo lives in LDS as
 // ready-made A fragments (54 KiB, linear in the lane index: conflict-free) and is read per tap - 10 LDS reads per 12 MFMAs in that pass,
 // 4 per 12 in the other two: the LDS runs at half its rate.
-template <int EPI, bool SPLIT>
+// XF (transform staging, split-precision kernels only): 0 - the input is DMA-staged from a [hi | lo] fp16 volume;  1 - it is an fp32 volume,
+// split on the way into LDS;  2 - it is lrelu(GroupNorm(y) [+ res]) of fp32 volumes, computed, split and (interior columns, with xf_out)
+// written back while it is staged.  Raw rows travel global -> registers (one step ahead) -> VALU -> ds_write, spread over the MFMA groups
+// of a step, where the VALU work hides under the matrix pipe.
+template <int EPI, bool SPLIT, int XF>
 __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
 {
+    static_assert(XF == 0 || (SPLIT && EPI == V_EPI_STAT), "transform staging exists for the split-precision statistics kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using R = VRing<SPLIT, EPI>;
     constexpr int K = R::K, RING = R::RING, QS = R::QS, IMG = R::IMG, NIMG = R::NIMG;
@@ -105,7 +115,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
     // vector-memory instructions per step, in issue order: DMA of input row h + K (and of residual row h + K), stores of row h - 1.  No
     // load of the loop returns into registers: hipcc drains vmcnt to 0 wherever a loop-carried load result is used, which would put a
     // full memory round trip into every step (the residual therefore goes through LDS as well).
-    constexpr int ND = 3 * NIMG + (EPI == V_EPI_RES ? 4 : 0), NR = 0, NS = EPI == V_EPI_F16 ? 2 : (EPI == V_EPI_RES ? 6 : 4);
+    constexpr int ND = XF ? 0 : 3 * NIMG + (EPI == V_EPI_RES ? 4 : 0), NR = 0, NS = EPI == V_EPI_F16 ? 2 : (EPI == V_EPI_RES ? 6 : 4);
     // End of step h: the DMA of row h + 2 (issued K - 2 steps ago, first thing of its step) must have landed.  vmcnt counts in order
     // (loads, LDS DMA and stores share the queue on gfx9: the compiler's own waits rest on the same fact), so "at most NW outstanding"
     // does it when NW never exceeds what was issued after that DMA: the residual loads and stores of its own step (compiler fences keep
@@ -214,9 +224,84 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
 #pragma unroll
             for (int q = 0; q < ND; ++q) stage_piece(r, slot, rslot, q);
         };
-        // row h0 - 1 + i lives in slot i (mod RING) of this item
+        // ---- transform staging (XF): thread t handles pieces idx = it * 256 + t of a row slab (640 pieces of 8 channels: column idx / 64, depth
+        // (idx / 4) % 16, channel group idx % 4 = t % 4 - consecutive threads read consecutive 32 bytes)
+        float4 xr[XF ? 3 : 1][2], xs[XF == 2 ? 3 : 1][2];       // raw row in flight: y [, res]
+        float xsc[XF == 2 ? 8 : 1], xsh[XF == 2 ? 8 : 1];
+        const int xq = tid & 3;
+        if constexpr (XF == 2) {
 #pragma unroll
-        for (int i = 0; i <= K; ++i) stage_row(h0 - 1 + i, i, i == 0 ? K : i - 1);       // residual rows h0 .. h0 + K - 1 in slots 0 .. K - 1 (row h0 - 1: dummy)
+            for (int r = 0; r < 8; ++r) {
+                const int c = xq * 8 + r;
+                const float mean = p.xf_stats[((long)n * 32 + c) * 2], rstd = p.xf_stats[((long)n * 32 + c) * 2 + 1];
+                xsc[r] = gn_scale(rstd, p.xf_gamma[c]);
+                xsh[r] = gn_shift(mean, xsc[r], p.xf_beta[c]);
+            }
+        }
+        auto xf_ok = [&](int r, int it) -> bool {
+            const int idx = it * 256 + tid, col = idx >> 6;
+            return idx < V_NC * 64 && (unsigned)r < (unsigned)p.H && r <= h1 && (unsigned)(w0 - 1 + col) < (unsigned)p.W;
+        };
+        auto xf_load = [&](int r, int it) {       // raw piece it of row r -> registers
+            if constexpr (XF != 0) {
+                const int idx = it * 256 + tid, col = idx >> 6, d = (idx >> 2) & 15;
+                xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
+                if constexpr (XF == 2) { xs[it][0] = xr[it][0]; xs[it][1] = xr[it][0]; }
+                if (xf_ok(r, it)) {
+                    const float* y = p.xf_y + ((long)n * p.xy_sN + (long)r * p.xy_sH + (long)(w0 - 1 + col) * p.xy_sW + d * 32 + xq * 8);
+                    xr[it][0] = *(const float4*)y; xr[it][1] = *(const float4*)(y + 4);
+                    if constexpr (XF == 2) {
+                        if (p.xf_res) {
+                            const float* x = p.xf_res + ((long)n * p.xr_sN + (long)r * p.xr_sH + (long)(w0 - 1 + col) * p.xr_sW + d * 32 + xq * 8);
+                            xs[it][0] = *(const float4*)x; xs[it][1] = *(const float4*)(x + 4);
+                        }
+                    }
+                }
+            }
+        };
+        auto xf_write = [&](int r, int slot, int it) {     // registers -> transform -> [hi | lo] images of ring slot `slot`
+            if constexpr (XF != 0) {
+                const int idx = it * 256 + tid, col = idx >> 6, d = (idx >> 2) & 15;
+                if (idx < V_NC * 64) {
+                    const bool ok = xf_ok(r, it);
+                    float a[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float v = ((const float*)&xr[it][k >> 2])[k & 3];
+                        if constexpr (XF == 2) a[k] = gn_lrelu(v, xsc[k], xsh[k], ((const float*)&xs[it][k >> 2])[k & 3], p.xf_slope);
+                        else a[k] = v;
+                        if (!ok) a[k] = 0.f;                 // zero padding applies to the conv's input, i.e. after the transform
+                    }
+                    h8_t hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { hi[k] = (half_t)a[k]; lo[k] = (half_t)(a[k] - (float)hi[k]); }
+                    unsigned char* dst = smem + xq * QS + slot * V_RS + col * V_CS + (d + 1) * 16;
+                    *(h8_t*)dst = hi; *(h8_t*)(dst + IMG) = lo;
+                    if constexpr (XF == 2) {
+                        // the transformed tensor is the new residual stream: every strip writes the rows and columns it owns
+                        if (p.xf_out && ok && col >= 1 && col <= V_TW && r >= h0 && r < h1) {
+                            float* o = p.xf_out + ((long)n * p.xo_sN + (long)r * p.xo_sH + (long)(w0 - 1 + col) * p.xo_sW + d * 32 + xq * 8);
+                            *(float4*)o = make_float4(a[0], a[1], a[2], a[3]); *(float4*)(o + 4) = make_float4(a[4], a[5], a[6], a[7]);
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (XF != 0) {
+            // rows h0 - 1, h0, h0 + 1 into slots 0 .. 2, then row h0 + 2 into the registers
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int it = 0; it < 3; ++it) xf_load(h0 - 1 + i, it);
+#pragma unroll
+                for (int it = 0; it < 3; ++it) xf_write(h0 - 1 + i, i, it);
+            }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) xf_load(h0 + 2, it);
+        } else {
+            // row h0 - 1 + i lives in slot i (mod RING) of this item
+#pragma unroll
+            for (int i = 0; i <= K; ++i) stage_row(h0 - 1 + i, i, i == 0 ? K : i - 1);       // residual rows h0 .. h0 + K - 1 in slots 0 .. K - 1 (row h0 - 1: dummy)
+        }
         TLS(0);
         __syncthreads();
         TLS(1);
@@ -322,7 +407,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 // assumes) are spread over the MFMA groups: a wave that issues them back to back waits for the address pipeline to take
                 // each one (150 - 350 cycles apiece at the head of a step) with nothing else to run; spread out, the residual-conv and
                 // split-precision kernels lose 18 % / 11 % of their cycles (profiles/r03_d_vol32_probe_spread.txt; -DV32_NOSPREAD is the A/B switch)
-                {
+                if constexpr (XF == 0) {
                     constexpr int NM = ND + NS;
 #pragma unroll
                     for (int m = G2 * NM / NG; m < (G2 + 1) * NM / NG; ++m) {
@@ -331,6 +416,14 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                         else if (have) store_piece(m - ND);
                         asm volatile("" ::: "memory");
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    // transform staging: row h + 2 (in registers since last step) -> slot sk after groups 0 / 2 / 4, the loads of row h + 3 after
+                    // groups 6 / 8 / 10, then the stores of row h - 1: every wait the compiler places at a conversion finds loads and stores that
+                    // are most of a step old
+                    if (G2 < 6 && (G2 & 1) == 0) xf_write(h + 2, sk, G2 >> 1);
+                    if (G2 >= 6 && G2 < 12 && (G2 & 1) == 0) xf_load(h + 3, (G2 - 6) >> 1);
+                    if (G2 >= 12 && G2 < 12 + NS && have) store_piece(G2 - 12);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
@@ -377,7 +470,9 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
             // row h + 2 has landed in this wave's part of the ring (counted wait: younger stores / DMA stay in flight); after the barrier in
             // everyone's, and everyone is done reading row h - 1
             TLS(5);
-            if (h > h0 + K - 2) wait_vm<NW>(); else wait_vm<NW0>();
+            if constexpr (XF != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's ds_writes of row h + 2 are in the LDS
+            else if (h > h0 + K - 2) wait_vm<NW>();
+            else wait_vm<NW0>();
             TLS(6);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -422,7 +517,12 @@ extern "C" void cs_debug_set_vol32_tl(void* buf, long cap) { g_v32_tl = (unsigne
 bool vol32_supported(const ConvParams& p)
 {
     if (p.KD != 3 || p.KH != 3 || p.KW != 3 || p.Cout_pad != 32 || p.Cout != 32 || p.D != 16 || p.inD != 16 || (p.W % V_TW) != 0) return false;
-    if (p.hilo ? (p.Cin != 96 || p.in_sD != 64) : (p.Cin != 32 || p.in_sD != 32)) return false;
+    if (p.xf_kind) {     // transform staging: fp32 source volumes instead of `in`
+        if (!p.hilo || p.Cin != 96 || !p.stat_out || (p.xf_kind != 1 && p.xf_kind != 2) || !p.xf_y.p || p.xf_y.sD != 32) return false;
+        if (p.xf_kind == 2 && (!p.xf_stats || !p.xf_gamma || !p.xf_beta)) return false;
+        if (p.xf_res.p && (p.xf_kind != 2 || p.xf_res.sD != 32)) return false;
+        if (p.xf_out.p && (p.xf_kind != 2 || p.xf_out.sD != 32)) return false;
+    } else if (p.hilo ? (p.Cin != 96 || p.in_sD != 64) : (p.Cin != 32 || p.in_sD != 32)) return false;
     if (p.up_shift || p.cg || p.wslot || p.sk_out || p.ragged || p.pixscale || p.stats) return false;
     if (p.act0 > ACT_LRELU || p.act1 > ACT_LRELU) return false;
     if (p.res.p && (!p.res_f32 || p.res.sD != 32)) return false;
@@ -444,7 +544,7 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     if (!vol32_supported(p)) { cs_set_error("vol32: not a 3x3x3 32 -> 32 convolution on a [N][H][W][16][32] volume this kernel supports"); return -1; }
     if (ep_check_extents(p, "vol32")) return -1;
     const long in_span = (long)(p.N - 1) * p.in_sN + (long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW + 1024;
-    if (in_span >= (1L << 31)) { cs_set_error("vol32: the input spans 2^31 elements or more"); return -1; }
+    if (!p.xf_kind && in_span >= (1L << 31)) { cs_set_error("vol32: the input spans 2^31 elements or more"); return -1; }
     if (!g_ncu) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
@@ -461,6 +561,17 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     k.out1 = (half_t*)p.out1.p; k.o1_sN = (int)p.out1.sN; k.o1_sH = (int)p.out1.sH; k.o1_sW = (int)p.out1.sW;
     k.s2 = p.s2; k.t2 = p.t2;
     k.stat_out = p.stat_out; k.stat_nblk = vol32_stat_nblk(p);
+    k.xf_y = (const float*)p.xf_y.p; k.xy_sN = (int)p.xf_y.sN; k.xy_sH = (int)p.xf_y.sH; k.xy_sW = (int)p.xf_y.sW;
+    k.xf_res = (const float*)p.xf_res.p; k.xr_sN = (int)p.xf_res.sN; k.xr_sH = (int)p.xf_res.sH; k.xr_sW = (int)p.xf_res.sW;
+    k.xf_out = (float*)p.xf_out.p; k.xo_sN = (int)p.xf_out.sN; k.xo_sH = (int)p.xf_out.sH; k.xo_sW = (int)p.xf_out.sW;
+    k.xf_stats = p.xf_stats; k.xf_gamma = p.xf_gamma; k.xf_beta = p.xf_beta; k.xf_slope = p.xf_slope;
+    if (p.xf_kind) {
+        const long lim = 1L << 31;
+        auto span = [&](const TDesc& t) { return (long)(p.N - 1) * t.sN + (long)(p.H - 1) * t.sH + (long)(p.W - 1) * t.sW + 512; };
+        if (span(p.xf_y) >= lim || (p.xf_res.p && span(p.xf_res) >= lim) || (p.xf_out.p && span(p.xf_out) >= lim)) {
+            cs_set_error("vol32: a transform-staging tensor spans 2^31 elements or more"); return -1;
+        }
+    }
 #ifdef V32_TL
     k.tl = g_v32_tl; k.tl_cap = g_v32_cap;
 #endif
@@ -487,11 +598,13 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     int r = -1;
     if (split) {
         if (epi != V_EPI_STAT) { cs_set_error("vol32: the split-precision kernel exists with the statistics epilogue only"); return -1; }
-        r = go(vol32_kernel<V_EPI_STAT, true>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+        if (p.xf_kind == 2) r = go(vol32_kernel<V_EPI_STAT, true, 2>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+        else if (p.xf_kind == 1) r = go(vol32_kernel<V_EPI_STAT, true, 1>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+        else r = go(vol32_kernel<V_EPI_STAT, true, 0>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
     } else {
-        if (epi == V_EPI_STAT) r = go(vol32_kernel<V_EPI_STAT, false>, VRing<false, V_EPI_STAT>::lds(V_EPI_STAT));
-        else if (epi == V_EPI_RES) r = go(vol32_kernel<V_EPI_RES, false>, VRing<false, V_EPI_RES>::lds(V_EPI_RES));
-        else r = go(vol32_kernel<V_EPI_F16, false>, VRing<false, V_EPI_F16>::lds(V_EPI_F16));
+        if (epi == V_EPI_STAT) r = go(vol32_kernel<V_EPI_STAT, false, 0>, VRing<false, V_EPI_STAT>::lds(V_EPI_STAT));
+        else if (epi == V_EPI_RES) r = go(vol32_kernel<V_EPI_RES, false, 0>, VRing<false, V_EPI_RES>::lds(V_EPI_RES));
+        else r = go(vol32_kernel<V_EPI_F16, false, 0>, VRing<false, V_EPI_F16>::lds(V_EPI_F16));
     }
     if (r) return r;
     hipError_t e = hipGetLastError();

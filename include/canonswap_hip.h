@@ -142,6 +142,13 @@ typedef struct cs_conv_desc {
     int ragged;               /* Cin % 32 == 16 and wgt went through cs_op_pair_ragged: paired taps in the last chunk (cfg 19 / 20 only) */
     int hilo;                 /* split-precision conv (util.py:528-544 convs of R): in = [hi | lo] per voxel, wgt = chunks W_hi | W_lo | W_hi, Cin = 96 */
     float* stat_out;          /* optional per-block partial (sum, sum of squares) of the stored fp32 out0 (cfg 30: [N][ceil(H/8) * W/2][32][2]) */
+    /* cfg 30 with hilo: transform staging - the conv input is computed from fp32 volumes (strides of out0) while it is staged instead of read
+     * from `in`: kind 1: xf_y; kind 2: lrelu((xf_y - mean) * rstd * gamma + beta [+ xf_res]) with (mean, rstd) = xf_stats[n][c][2], written back to
+     * xf_out when given (util.py:531-540 fused into the consumer conv) */
+    int xf_kind;
+    const float* xf_y; const float* xf_res; float* xf_out;
+    const float* xf_stats; const float* xf_gamma; const float* xf_beta;
+    float xf_slope;
 } cs_conv_desc;
 int cs_op_conv(const cs_conv_desc* d, void* stream);
 /* in place: re-pack the last 32-channel chunk of a packed conv weight [chunks * taps][Cout_pad][32] (Cin % 32 == 16) so that two

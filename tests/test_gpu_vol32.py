@@ -172,3 +172,75 @@ def test_vol32_split_precision_with_statistics(N, H, W):
         want[:, hb, :, :, 1] = (blk ** 2).sum(dim=(1, 3, 4))
     got = part.double().cpu().view(N, Hb, W // 2, Cc, 2)
     assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("kind,with_res", [(1, False), (2, False), (2, True)])
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (3, 16, 8)])
+def test_vol32_transform_staging(kind, with_res, N, H, W):
+    """Transform staging (ConvParams::xf_*): the GroupNorm apply + residual + LeakyReLU of util.py:531-540 (kind 2) or the plain hi / lo split
+    (kind 1) happens while the split-precision conv stages its input.  Reference: the same transform in torch fp32, split into [hi | lo] and
+    run through the DMA-staged kernel; the transformed tensor written back (the new residual stream) against torch.  The transform itself
+    is checked bit for bit at engine level (test below); here 1 ulp of the fp32 transform may differ, so 2e-6."""
+    import hip_ops as ops
+    r = _rng(9000 + 10 * kind + int(with_res) + N + H + W)
+    Cc, D = 32, 16
+    y = _randn(r, N, H, W, D, Cc)
+    res = _randn(r, N, H, W, D, Cc)
+    w = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04)
+    b = _randn(r, Cc, scale=0.1)
+    mean, rstd = _randn(r, N, Cc, scale=0.3), torch.from_numpy(r.uniform(0.5, 2.0, (N, Cc)).astype(np.float32))
+    gamma, beta = torch.from_numpy(r.uniform(0.5, 1.5, Cc).astype(np.float32)), _randn(r, Cc, scale=0.2)
+    stats = torch.stack([mean, rstd], dim=2).contiguous()
+    if kind == 2:
+        a = (y - mean.view(N, 1, 1, 1, Cc)) * rstd.view(N, 1, 1, 1, Cc) * gamma + beta + (res if with_res else 0)
+        a = F.leaky_relu(a, 0.01)
+    else:
+        a = y.clone()
+    hi = a.half(); lo = (a - hi.float()).half()
+    x2 = torch.cat([hi, lo], dim=-1).contiguous().to(DEV)
+    whi = w.half().float(); wlo = (w - whi).half().float()
+    wp = ops.packed_weight(torch.cat([whi, wlo, whi], dim=1), 32, DEV)
+    nblk = ((H + 7) // 8) * (W // 2)
+
+    def run(xf):
+        out = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float32, device=DEV)
+        part = torch.zeros(N, nblk, Cc, 2, dtype=torch.float32, device=DEV)
+        ops.conv(_view(x2), wp, 32, 32, (3, 3, 3), cin=96, bias=b.to(DEV), out0=_view(out), cfg=CFG_VOL32, hilo=True, stat_out=part, xf=xf)
+        torch.cuda.synchronize()
+        return out, part
+
+    ref, ref_part = run(None)
+    yd, resd = y.to(DEV), res.to(DEV)
+    wb = torch.full((N, H, W, D, Cc), -9.0, dtype=torch.float32, device=DEV)
+    xf = dict(kind=kind, y=yd)
+    if kind == 2:
+        xf.update(stats=stats.to(DEV), gamma=gamma.to(DEV), beta=beta.to(DEV), slope=0.01, res=resd if with_res else None, out=wb)
+    got, got_part = run(xf)
+    assert ops.rel_err(got, ref) < 2e-6
+    assert float((got_part - ref_part).abs().max() / ref_part.abs().max()) < 1e-5
+    if kind == 2:
+        assert float((wb.cpu() - a).abs().max()) < 1e-5         # every voxel of the new residual stream written, once
+    assert bool((yd.cpu() == y).all())
+
+
+def test_engine_refine_with_and_without_transform_staging(state_dicts):
+    """R (adaptive_modulate.py:721-733) with the GroupNorm apply inside the conv staging (default) against the stand-alone norm_act / split16
+    passes (CANONSWAP_VOL32_XF=0, second engine in a subprocess): both use the same fixed operation sequence (common.h gn_lrelu), the
+    convs and their statistics are the same kernels - identical bits."""
+    import os
+    import subprocess
+    import sys
+    from canonswap_amd.can_swap_e2e import can_swapper
+    r = _rng(21)
+    f = torch.from_numpy((0.08 * r.standard_normal((2, 32, 16, 64, 64))).astype(np.float32))
+    torch.save(f, "/tmp/xf_in.pt")
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=2)
+    got = sw.refine_module(f.cuda()).cpu()
+    code = ("import torch, sys; sys.path.insert(0, %r); from canonswap_amd import synth; from canonswap_amd.can_swap_e2e import can_swapper;"
+            "sd = synth.to_torch(synth.make_state_dicts(0)); sw = can_swapper(None, state_dicts=sd, max_batch=2);"
+            "torch.save(sw.refine_module(torch.load('/tmp/xf_in.pt').cuda()).cpu(), sys.argv[1])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CANONSWAP_VOL32_XF="0")
+    rr = subprocess.run([sys.executable, "-c", code, "/tmp/xf_off.pt"], env=env, capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stderr[-2000:]
+    want = torch.load("/tmp/xf_off.pt")
+    assert torch.equal(got, want), float((got - want).abs().max())
