@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "vol32.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "vol32.hip", "vol32_fused.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
 # test-only cross-check kernel (the first-generation implicit-GEMM conv): its own library, never linked into the product
 TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "csrc", "test_igemm.hip")
 TEST_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcanonswap_test.so")
@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_unpack_u8", "cs_soft_erosion", "cs_prepare_crops", "cs_warp_affine_u8", "cs_warp_affine_f32", "cs_paste_back",
     "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
-    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged",
+    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged", "cs_op_resblock3d",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -241,6 +241,7 @@ def load():
     lib.cs_op_grid_sample3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.cs_op_chan_stats.argtypes = [vp, ci, ci, C.c_long, ci, cf, vp, vp, vp]
     lib.cs_op_pair_ragged.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+    lib.cs_op_resblock3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp]
     lib.cs_op_chan_stats_partial_floats.argtypes = [ci, C.c_long, ci]
     lib.cs_op_chan_stats_partial_floats.restype = C.c_long
     _lib = lib

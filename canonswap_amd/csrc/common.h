@@ -142,6 +142,19 @@ void cs_set_error(const char* fmt, ...);
 int launch_conv(const ConvParams& p, int cfg, int mode, hipStream_t st);   // tests/csrc/conv_igemm.hip: test-only library
 int launch_conv_halo(const ConvParams& p, int cfg, int ck, int mode, hipStream_t st);
 // vol32.hip: the 3x3x3 32 -> 32 convolutions on [N][H][W][16][32] volumes (weights in registers, persistent workgroups marching along H)
+// vol32_fused.hip: one whole ResBlock3d (util.py:80-102) of the feature volume as one launch: out0 = conv2(relu(conv1(a) + b1)) + b2 + x,
+// out1 = act1(out0 * s2 + t2); BatchNorms folded into the weights / biases / (s2, t2) at load time.  All four volumes are
+// [N][H][W][16][32] with the same element strides (sN, sH, sW; a column of 16 voxels x 32 channels contiguous); a, out1 fp16; x, out0 fp32.
+struct ResBlock3dCall {
+    const half_t* a; const float* x; float* out0; half_t* out1;
+    long sN, sH, sW;
+    const half_t* w1; const half_t* w2;          // packed [27][32][32]
+    const float* b1; const float* b2; const float* s2; const float* t2;
+    int act1; float slope1;
+    int N, H, W;
+};
+bool vol32_fused_supported(const ResBlock3dCall& c);
+int launch_vol32_fused(const ResBlock3dCall& c, hipStream_t st);
 bool vol32_supported(const ConvParams& p);
 int vol32_stat_nblk(const ConvParams& p);        // partial-statistics blocks per sample when ConvParams::stat_out is set
 int launch_vol32(const ConvParams& p, hipStream_t st);

@@ -427,9 +427,33 @@ int do_stats(cs_engine* e, const void* x, int is_f32, int B, long P, int C, floa
 
 // ------------------------------------------------------------------------------------------------ F
 // AppearanceFeatureExtractor.forward (appearance_feature_extractor.py:38-48); result: fp32 HWDC in vs[*cur]
+// whole ResBlock3d per launch (vol32_fused.hip; CANONSWAP_VOL32_FUSED=0: A/B knob, two vol32 / conv_halo launches per block)
+bool vol32_fused_on() { static const bool on = [] { const char* s = getenv("CANONSWAP_VOL32_FUSED"); return !s || atoi(s) != 0; }(); return on && vol32_enabled(); }
+
 int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Affine* final_post, int final_act, hipStream_t st)
 {
     // util.py:94-102; a = relu(bn1(x)) is already in va[0]; x (fp32 residual stream) in vs[*cur]
+    if (vol32_fused_on()) {
+        // block i reads a from va[i & 1] and leaves the next block's a in va[(i + 1) & 1] (a neighbouring workgroup still reads the halo
+        // columns of the input while this one stores): six blocks end in va[0] again
+        for (int i = 0; i < 6; ++i) {
+            const int nxt = (*cur + 1) % 3;
+            ResBlock3dCall c;
+            c.a = e->va[i & 1]; c.x = e->vs[*cur]; c.out0 = e->vs[nxt]; c.out1 = e->va[(i + 1) & 1];
+            c.sN = VOL; c.sH = (long)FW * FD * FC; c.sW = (long)FD * FC;
+            c.w1 = rb[i].c1.w; c.w2 = rb[i].c2.w; c.b1 = rb[i].c1.b; c.b2 = rb[i].c2.b;
+            c.s2 = nullptr; c.t2 = nullptr; c.act1 = ACT_NONE; c.slope1 = 0.f;
+            if (i < 5) { c.s2 = rb[i].post.s; c.t2 = rb[i].post.t; c.act1 = ACT_RELU; }
+            else if (final_post) { c.s2 = final_post->s; c.t2 = final_post->t; c.act1 = final_act; }
+            c.N = B; c.H = FH; c.W = FW;
+            const double fl = 2.0 * (rb[i].c1.macs_per_pos + rb[i].c2.macs_per_pos) * (double)B * VOX;
+            e->flops += fl;
+            e->flops_exec += 2.0 * 2.0 * (double)B * VOX * 32 * 32.0 * 27;
+            TRY(e->run(0, st, [&] { return launch_vol32_fused(c, st); }, (rb[i].c1.name + "+c2").c_str(), fl));
+            *cur = nxt;
+        }
+        return 0;
+    }
     for (int i = 0; i < 6; ++i) {
         ConvCall c1 = mk(rb[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);   // conv1 with norm2 folded, ReLU
         c1.p.act0 = ACT_RELU;
@@ -1500,6 +1524,17 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     }
     cs_set_error("cs_op_conv: cfg %d is not a conv_halo configuration (the conv_igemm cross-check kernel lives in the test-only library)", d->cfg);
     return -1;
+}
+
+extern "C" int cs_op_resblock3d(const void* a, const float* x, float* out0, void* out1, int N, int H, int W, const void* w1, const void* w2,
+                                const float* b1, const float* b2, const float* s2, const float* t2, int act1, float slope1, void* stream)
+{
+    ResBlock3dCall c;
+    c.a = (const half_t*)a; c.x = x; c.out0 = out0; c.out1 = (half_t*)out1;
+    c.sN = (long)H * W * 512; c.sH = (long)W * 512; c.sW = 512;
+    c.w1 = (const half_t*)w1; c.w2 = (const half_t*)w2; c.b1 = b1; c.b2 = b2; c.s2 = s2; c.t2 = t2; c.act1 = act1; c.slope1 = slope1;
+    c.N = N; c.H = H; c.W = W;
+    return launch_vol32_fused(c, (hipStream_t)stream);
 }
 
 extern "C" int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream)

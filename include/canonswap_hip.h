@@ -155,6 +155,10 @@ int cs_op_conv(const cs_conv_desc* d, void* stream);
  * taps that are neighbours along the row share one 32-deep K-step (what the engine does for the hourglass tail, the mask conv and the
  * first encoder block at load time; dense_motion.py:88, util.py:185-190,261-263) */
 int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream);
+/* one ResBlock3d of a feature volume (util.py:80-102, BatchNorms folded): contiguous [N][H][W][16][32] volumes a (fp16), x (fp32) ->
+ * out0 (fp32) = conv2(relu(conv1(a) + b1)) + b2 + x, out1 (fp16) = act1(out0 * s2 + t2); w1 / w2 packed like every 3x3x3 32 -> 32 weight */
+int cs_op_resblock3d(const void* a, const float* x, float* out0, void* out1, int N, int H, int W, const void* w1, const void* w2,
+                     const float* b1, const float* b2, const float* s2, const float* t2, int act1, float slope1, void* stream);
 int cs_op_grid_sample3d(const float* in_hwdc, const float* grid, float* out32, void* out16, int N, int D, int H, int W,
                         void* stream);
 /* per-(n,c) mean and 1/sqrt(var+eps) of a [N][P][C] tensor; partials: scratch of cs_op_chan_stats_partial_floats floats */

@@ -244,3 +244,76 @@ def test_engine_refine_with_and_without_transform_staging(state_dicts):
     assert rr.returncode == 0, rr.stderr[-2000:]
     want = torch.load("/tmp/xf_off.pt")
     assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def _resblock_fused(a16, x32, w1p, w2p, b1, b2, s2, t2, act1):
+    import ctypes as C
+    from canonswap_amd import _lib
+    lib = _lib.load()
+    N, H, W, D, Cc = a16.shape
+    out0 = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float32, device=DEV)
+    out1 = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float16, device=DEV)
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.cs_op_resblock3d(p(a16), p(x32), p(out0), p(out1), N, H, W, p(w1p), p(w2p), p(b1), p(b2), p(s2), p(t2),
+                                    {"none": 0, "relu": 1}[act1], 0.0, st), "cs_op_resblock3d")
+    torch.cuda.synchronize()
+    return out0, out1
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 64, 64), (32, 64, 64), (1, 64, 64), (2, 24, 16), (5, 2, 8), (1, 1, 8), (2, 9, 24)])
+@pytest.mark.parametrize("post", [True, False])
+def test_fused_resblock3d_equals_two_launches(N, H, W, post):
+    """vol32_fused.hip: a whole ResBlock3d (util.py:80-102) per launch against conv1 -> conv2 as two vol32 launches (which equal the halo
+    kernel bit for bit, tests above): torch.equal on both outputs, and against torch fp32 at the usual tolerance."""
+    import hip_ops as ops
+    r = _rng(3000 + 7 * N + 3 * H + W + int(post))
+    Cc, D = 32, 16
+    x = _randn(r, N, Cc, D, H, W)
+    a = torch.relu(_randn(r, N, Cc, D, H, W))
+    w1 = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04); w2 = _randn(r, Cc, Cc, 3, 3, 3, scale=0.04)
+    b1 = _randn(r, Cc, scale=0.1); b2 = _randn(r, Cc, scale=0.1)
+    s2 = torch.from_numpy(r.uniform(0.5, 1.5, Cc).astype(np.float32)) if post else None
+    t2 = _randn(r, Cc, scale=0.2) if post else None
+    a16 = _hwdc(a).half().to(DEV); x32 = _hwdc(x).to(DEV)
+    w1p, w2p = ops.packed_weight(w1, 32, DEV), ops.packed_weight(w2, 32, DEV)
+    dv = lambda t: None if t is None else t.to(DEV)
+    got0, got1 = _resblock_fused(a16, x32, w1p, w2p, dv(b1), dv(b2), dv(s2), dv(t2), "relu" if post else "none")
+    # two launches
+    h, _ = _run(CFG_VOL32, a16, w1p, dv(b1), None, None, None, True)
+    out0 = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float32, device=DEV)
+    out1 = torch.full((N, H, W, D, Cc), 3.0, dtype=torch.float16, device=DEV)
+    ops.conv(_view(h), w2p, 32, 32, (3, 3, 3), bias=dv(b2), res=_view(x32), out0=_view(out0), s2=dv(s2), t2=dv(t2),
+             act1="relu" if post else "none", out1=_view(out1), cfg=CFG_VOL32)
+    torch.cuda.synchronize()
+    assert torch.equal(got0, out0), float((got0 - out0).abs().max())
+    assert torch.equal(got1, out1)
+    hh = F.relu(F.conv3d(a.half().float(), w1.half().float(), b1, padding=1)).half().float()
+    y = F.conv3d(hh, w2.half().float(), b2, padding=1) + x
+    assert ops.rel_err(_back(got0), y) < 2e-3
+
+
+def test_engine_feature_extractor_fused_vs_two_launches(state_dicts):
+    """F (appearance_feature_extractor.py:38-48: six ResBlock3d) and T's six through the engine with the fused kernel (default) and with two
+    launches per block (CANONSWAP_VOL32_FUSED=0, subprocess): identical bits."""
+    import os
+    import subprocess
+    import sys
+    from canonswap_amd import synth
+    from canonswap_amd.can_swap_e2e import can_swapper
+    inp = synth.make_frame_inputs(3, seed=33, size=256)
+    img = torch.from_numpy(inp["img"])
+    idv = torch.from_numpy(synth.make_identity(7))
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=3)
+    f = sw.extract_feature_3d(img.cuda())
+    got = torch.cat([f.cpu(), sw.swap_module(f, idv.cuda()).cpu()])
+    code = ("import torch, sys; sys.path.insert(0, %r); from canonswap_amd import synth; from canonswap_amd.can_swap_e2e import can_swapper;"
+            "sd = synth.to_torch(synth.make_state_dicts(0)); sw = can_swapper(None, state_dicts=sd, max_batch=3);"
+            "img = torch.from_numpy(synth.make_frame_inputs(3, seed=33, size=256)['img']); idv = torch.from_numpy(synth.make_identity(7));"
+            "f = sw.extract_feature_3d(img.cuda()); torch.save(torch.cat([f.cpu(), sw.swap_module(f, idv.cuda()).cpu()]), sys.argv[1])"
+            ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CANONSWAP_VOL32_FUSED="0")
+    r = subprocess.run([sys.executable, "-c", code, "/tmp/fused_off.pt"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = torch.load("/tmp/fused_off.pt")
+    assert torch.equal(got, want), float((got - want).abs().max())

@@ -57,6 +57,26 @@ def main():
         "split + stats": lambda: ops.conv(x2, w3, 32, 32, (3, 3, 3), cin=96, bias=b, out0=vol(B, dtype=torch.float32), cfg=a.cfg, hilo=True,
                                           stat_out=torch.empty(B * 256 * 64, dtype=torch.float32, device=DEV) if a.cfg == 30 else None, **kw),
     }
+    # the fused ResBlock3d kernel (vol32_fused.hip)
+    import ctypes as CC
+    tlf = None
+    if hasattr(lib, "cs_debug_set_vol32f_tl"):
+        tlf = torch.zeros(4096 * 12, dtype=torch.int64, device=DEV)
+        lib.cs_debug_set_vol32f_tl.argtypes = [CC.c_void_p, CC.c_long]
+        lib.cs_debug_set_vol32f_tl(CC.c_void_p(tlf.data_ptr()), 4096)
+    xa = torch.relu(torch.randn(B, 64, 64, 16, 32, device=DEV)).half()
+    xr = torch.randn(B, 64, 64, 16, 32, device=DEV)
+    o0 = torch.empty_like(xr); o1 = torch.empty_like(xa)
+    w2 = torch.from_numpy((r.standard_normal((27, 32, 32)) * 0.02).astype(np.float16)).to(DEV)
+    pp = lambda t: CC.c_void_p(t.data_ptr())
+    stream = lambda: CC.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fused():
+        _lib.check(lib.cs_op_resblock3d(pp(xa), pp(xr), pp(o0), pp(o1), B, 64, 64, pp(w), pp(w2), pp(b), pp(b), pp(b), pp(b), 1, 0.0, stream()), "resblock")
+
+    if a.cfg == 30:
+        cases["fused ResBlock3d (c1 + c2)"] = fused
+    FPH = ["startup", "prologue", "compute", "memory instr", "epilogue", "lgkm wait", "vm wait", "barrier", "step head", "tail"]
     gfl = 2 * 27 * 32 * 32 * B * 65536 / 1e9
     for name, fn in cases.items():
         for _ in range(3):
@@ -71,7 +91,19 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.reps
         print(f"{name:28s} {us:8.1f} us/launch  {gfl / us / 1e3:7.1f} TFLOP/s algorithmic ({gfl / us / 1e3 / 2500:.3f} of peak)")
-        if tl is not None:
+        if tlf is not None and name.startswith("fused"):
+            tlf.zero_()
+            fn()
+            torch.cuda.synchronize()
+            t = tlf.view(-1, 12).cpu().numpy()
+            t = t[t[:, 10] > 0]
+            for role in (0, 1):
+                q = t[t[:, 11] == role]
+                life = q[:, :10].sum(axis=1)
+                print(f"   role {'conv2' if role else 'conv1'}: waves {len(q)}, steps {q[:, 10].mean():.1f}, life {life.mean():.0f} cycles")
+                print("      per step: " + "  ".join(f"{FPH[i]} {q[:, i].mean() / q[:, 10].mean():.0f}" for i in range(2, 9)))
+            continue
+        if tl is not None and not name.startswith("fused"):
             tl.zero_()
             fn()
             torch.cuda.synchronize()
