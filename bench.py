@@ -30,7 +30,10 @@ if ROOT not in sys.path:
 
 ALGO_GFLOP_PER_FRAME = 2374.3      # 2*MAC of every conv on the primary path, as the reference runs it
 PEAK_TFLOPS_F16 = 2500.0           # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
-WARP_BYTES_PER_FRAME = 2 * 17.56e6 + 4.19e6      # two fp32 feature warps (8.39 MB in + 0.79 MB grid + 8.39 MB out) + one fp16 copy
+# SURVEY 8d, HBM row of the path: per frame two trilinear feature warps (warping_network.py:46-62) of the fp32 volume (8.39 MB in + 8.39 MB
+# out each; + one 4.19 MB fp16 copy; the sampling grid costs 0 bytes: it is consumed inside the kernel that computes it) and, in the same
+# kernel, the softmax over the 22 mask logits that yields the deformation (dense_motion.py:88-94: 22 x 65536 x 4 B = 5.77 MB of logits per call)
+WARP_BYTES_PER_FRAME = 2 * (16.78e6 + 5.77e6) + 4.19e6
 
 
 def _free_port():
@@ -324,9 +327,10 @@ def main():
                          "other_kernels_ms_per_step": round((prof["other_ms"] + prof["warp_ms"]) / K, 3),
                          "conv_ms_per_step": round(prof["conv_ms"] / K, 3),
                          "end_to_end_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / world / (PEAK_TFLOPS_F16 * 1e12), 4)},
-            # the HBM-bound row of the path: trilinear feature warp (F.grid_sample, warping_network.py:46-47), fp32 volumes:
-            # algorithmic bytes per frame and call = 8.39 MB in + 0.79 MB grid + 8.39 MB out (+ 4.19 MB fp16 copy on the first call)
-            "warp_roofline": {"bound": "hbm", "kernel": "grid_sample_kernel",
+            # the HBM-bound row of the path: softmax -> deformation -> trilinear feature warp in one kernel (dm_softmax_warp_kernel)
+            "warp_roofline": {"bound": "hbm", "kernel": "dm_softmax_warp_kernel (mask softmax + deformation + feature warp; the logits arrive as 7 x 22 "
+                                                        "fp32 partials per voxel from the mask conv: 7x the algorithmic 5.77 MB)",
+                              "algorithmic_mb_per_frame": round(WARP_BYTES_PER_FRAME / 1e6, 2),
                               "achieved": round(WARP_BYTES_PER_FRAME * plan.n_local * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s",
                               "frac": round(WARP_BYTES_PER_FRAME * plan.n_local * K / (prof["warp_ms"] / 1e3) / 8e12, 4),

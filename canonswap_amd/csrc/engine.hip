@@ -497,7 +497,12 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 // ------------------------------------------------------------------------------------------------ W
 // DenseMotionNetwork.forward (dense_motion.py:67-104). feat: fp32 HWDC. Leaves deformation / occlusion in
 // e->dm_deform / e->dm_occ.
-int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st)
+// warp_in / warp_o32 / warp_o16: when given, the feature warp that consumes the deformation (warping_network.py:46-62) is part of the softmax
+// kernel (dm_softmax_warp_kernel): the caller launches no grid_sample.
+bool warp_fused() { static const bool on = [] { const char* s = getenv("CANONSWAP_WARP_FUSED"); return !s || atoi(s) != 0; }(); return on; }
+
+int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st,
+                     const float* warp_in = nullptr, float* warp_o32 = nullptr, half_t* warp_o16 = nullptr)
 {
     TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, B, FD, FH, FW, st); }, "dm_compress"));
     e->flops += 2.0 * 32 * 4 * VOX * B;
@@ -554,7 +559,13 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         static const bool wide = getenv("CANONSWAP_MASK_TILE8") != nullptr;
         TRY(go(e, m, st, wide ? 8 : 2, 8));
     }
-    TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
+    if (warp_in && !mask_out && warp_fused()) {
+        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, e->dm_deform, B, FD, FH, FW, st); },
+                   "dm_softmax_warp"));
+    } else {
+        TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
+        if (warp_in) TRY(e->run(2, st, [&] { return launch_grid_sample(warp_in, e->dm_deform, warp_o32, warp_o16, B, FD, FH, FW, st); }, "grid_sample"));
+    }
     // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose
     // input channels are grouped by depth slice (16 groups of 144 channels at stride sD) and whose 7 output channels are the
     // 7 horizontal taps (summed by occ_finish_kernel).
@@ -1224,8 +1235,7 @@ extern "C" int cs_warp(cs_engine* e, int B, const float* f, const float* kp_sour
     ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
-    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
-    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, e->vs[1], nullptr, B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st, e->vs[0], e->vs[1], nullptr));      // dense motion + the feature warp it drives
     TRY(from_hwdc(e, B, e->vs[1], f_out, st));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
     return 0;
@@ -1274,8 +1284,7 @@ extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float*
     ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
-    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st));
-    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st, e->vs[0], nullptr, e->va[0]));      // dense motion + the feature warp it drives
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     if (seg_out) TRY(e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }, "nhwc16_to_nchw"));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));
@@ -1330,9 +1339,8 @@ extern "C" int cs_swap_frames_ids(cs_engine* e, const int* slots, int B, const f
     int cur = 0;
     TRY(run_F(e, B, img, &cur, st));                                                      // :242 f_s
     // :244 warp(f_s, kp_source = x_t, kp_driving = x_can)
-    TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_can, /*kp_s*/ x_t, nullptr, st));
     const int nxt = (cur + 1) % 3;
-    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, e->vs[nxt], e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_can, /*kp_s*/ x_t, nullptr, st, e->vs[cur], e->vs[nxt], e->va[0]));      // dense motion + the feature warp it drives
     cur = nxt;
     // the first warp's occlusion map is reused by the debug decodes (:248,:257); keep a copy in tmask-free storage
     float* occ1 = e->img_b;   // B*4096 floats fit easily
@@ -1348,8 +1356,7 @@ extern "C" int cs_swap_frames_ids(cs_engine* e, const int* slots, int B, const f
     }
     TRY(run_R(e, B, &cur, st));                                                             // :262
     // :263 warp_decode(f, kp_source = x_can, kp_driving = x_t)
-    TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_t, /*kp_s*/ x_can, nullptr, st));
-    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[cur], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(run_dense_motion(e, B, e->vs[cur], /*kp_d*/ x_t, /*kp_s*/ x_can, nullptr, st, e->vs[cur], nullptr, e->va[0]));      // dense motion + the feature warp it drives
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     float* dst = out_f32 ? out_f32 : e->img_a;
     TRY(run_G(e, B, e->seg16, dst, st));
@@ -1372,8 +1379,7 @@ extern "C" int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, co
         for (int b = 0; b < B; ++b) TRY(copy_dd(e->kpbuf + (size_t)b * 63, kp_source, 63 * 4, st));
         ks = e->kpbuf;
     }
-    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, ks, nullptr, st));
-    TRY(e->run(2, st, [&] { return launch_grid_sample(e->vs[0], e->dm_deform, nullptr, e->va[0], B, FD, FH, FW, st); }, "grid_sample"));
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, ks, nullptr, st, e->vs[0], nullptr, e->va[0]));      // dense motion + the feature warp it drives
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     float* dst = out_f32 ? out_f32 : e->img_a;
     TRY(run_G(e, B, e->seg16, dst, st));

@@ -292,6 +292,106 @@ int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, c
     return 0;
 }
 
+// dm_softmax + the feature warp that consumes its deformation in ONE kernel (dense_motion.py:88-94 -> warping_network.py:46-62): the
+// sampling grid never goes through HBM (SURVEY 8d prices it at 0 bytes then) and one dependent launch disappears.  A workgroup owns the
+// 16 (w) x 16 (d) voxels of one (n, h): phase 1, one thread per voxel, is dm_softmax_kernel's arithmetic verbatim (same order of
+// operations: same bits) and leaves (x, y, z) in LDS; phase 2 gathers with 8 lanes x float4 per voxel exactly like grid_sample_kernel,
+// voxels in (w, d) order so that a wave writes 8 consecutive depth slices of one column = 1 KiB contiguous.  XCD-aware block order:
+// every XCD walks a contiguous eighth of the output (neighbouring voxels share source lines: they meet in one L2).
+__global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                              const float* __restrict__ kp_d, const float* __restrict__ kp_s,
+                                                              const float* __restrict__ in, float* __restrict__ out32, half_t* __restrict__ out16,
+                                                              float* __restrict__ deform, int N, int D, int H, int W)
+{
+    __shared__ float defs[256 * 3];
+    long blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int nwb = W >> 4;
+    const int wb = (int)(blk % nwb); long r = blk / nwb;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    const int t = threadIdx.x;
+    {   // ---- phase 1: softmax over the 22 mask logits and the motion blend for voxel (d, x) = (t >> 4, wb * 16 + (t & 15))
+        const int d = t >> 4, x = wb * 16 + (t & 15);
+        const long v = (((long)n * D + d) * H + y) * W + x;
+        float l[22];
+#pragma unroll
+        for (int k = 0; k < 22; ++k) l[k] = bias[k];
+#pragma unroll
+        for (int kw = 0; kw < 7; ++kw) {
+            const int xx = x + kw - 3;
+            if ((unsigned)xx < (unsigned)W) {
+                const float2* src = (const float2*)(part + (v + kw - 3) * 160 + kw * 22);
+#pragma unroll
+                for (int j = 0; j < 11; ++j) { const float2 q = src[j]; l[2 * j] += q.x; l[2 * j + 1] += q.y; }
+            }
+        }
+        float mx = l[0];
+#pragma unroll
+        for (int k = 1; k < 22; ++k) mx = fmaxf(mx, l[k]);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 22; ++k) { l[k] = __expf(l[k] - mx); sum += l[k]; }
+        const float inv = 1.f / sum;
+        const float gx = grid_coord(x, W), gy = grid_coord(y, H), gz = grid_coord(d, D);
+        float ox = gx * (l[0] * inv), oy = gy * (l[0] * inv), oz = gz * (l[0] * inv);
+#pragma unroll
+        for (int k = 1; k < 22; ++k) {
+            const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
+            const float* ps = kp_s + ((long)n * 21 + (k - 1)) * 3;
+            const float m = l[k] * inv;
+            ox = fmaf(m, (gx - pd[0]) + ps[0], ox);
+            oy = fmaf(m, (gy - pd[1]) + ps[1], oy);
+            oz = fmaf(m, (gz - pd[2]) + ps[2], oz);
+        }
+        defs[t * 3] = ox; defs[t * 3 + 1] = oy; defs[t * 3 + 2] = oz;
+        if (deform) { float* o = deform + v * 3; o[0] = ox; o[1] = oy; o[2] = oz; }
+    }
+    __syncthreads();
+    // ---- phase 2: trilinear gather (grid_sample_kernel's arithmetic), voxel j = (w, d) = (j >> 4, j & 15) -> 8 lanes x float4
+    const int cg = t & 7;
+    const float* base = in + (long)n * H * W * D * 32 + cg * 4;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int j = it * 32 + (t >> 3), wl = j >> 4, d = j & 15;
+        const float* g = defs + ((d << 4) | wl) * 3;
+        const float ix = ((g[0] + 1.f) * W - 1.f) * 0.5f, iy = ((g[1] + 1.f) * H - 1.f) * 0.5f, iz = ((g[2] + 1.f) * D - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+        const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
+                    if ((unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D) {
+                        const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                        const float4 c = *(const float4*)(base + (((long)yc * W + xc) * D + zc) * 32);
+                        a[0] = fmaf(wgt, c.x, a[0]); a[1] = fmaf(wgt, c.y, a[1]); a[2] = fmaf(wgt, c.z, a[2]); a[3] = fmaf(wgt, c.w, a[3]);
+                    }
+                }
+        const long vo = ((((long)n * H + y) * W + wb * 16 + wl) * D + d) * 32 + cg * 4;
+        if (out32) *(float4*)(out32 + vo) = make_float4(a[0], a[1], a[2], a[3]);
+        if (out16) {
+            h4_t o; o[0] = (half_t)a[0]; o[1] = (half_t)a[1]; o[2] = (half_t)a[2]; o[3] = (half_t)a[3];
+            *(h4_t*)(out16 + vo) = o;
+        }
+    }
+}
+
+int launch_dm_softmax_warp(const float* part, const float* bias, const float* kp_d, const float* kp_s, const float* in, float* out32,
+                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st)
+{
+    if (D != 16 || (W & 15)) { cs_set_error("dm_softmax_warp: depth 16 and a width that is a multiple of 16"); return -1; }
+    hipLaunchKernelGGL(dm_softmax_warp_kernel, dim3((unsigned)((long)N * H * (W >> 4))), dim3(256), 0, st, part, bias, kp_d, kp_s, in,
+                       out32, out16, deform, N, D, H, W);
+    LAUNCH_CHECK("dm_softmax_warp");
+    return 0;
+}
+
 // occlusion map, second half (dense_motion.py:98-102). The 7x7 conv over the (c,d)-flattened prediction is run
 // on the MFMA conv kernel as a depth-collapsing (16 x 7 x 1)-tap conv whose 7 output channels are the 7
 // horizontal taps: part[n][y][xin][kx] = sum_{d,ky,c} pred[d][y+ky-3][xin][c] * w[c*16+d][ky][kx].
@@ -326,7 +426,12 @@ __global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restric
                                                           float* __restrict__ out32, half_t* __restrict__ out16, int N, int D, int H, int W)
 {
     const long total = (long)N * H * W * D * 8;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order: hardware places workgroup b on XCD b % 8 (each with its own L2); every XCD walks a contiguous eighth of the
+    // output, so the source lines that neighbouring output voxels share (the 8 corners of adjacent voxels overlap) are fetched into ONE
+    // L2 instead of up to eight (r02: 2.1x over-fetch on the read side, profiles/r02_i_pmc_summary.csv)
+    long blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    long i = blk * 256 + threadIdx.x;
     if (i >= total) return;
     const int cg = i & 7; long v = i >> 3;     // v: voxel index in HWDC order
     const int d = v % D; long r = v / D;

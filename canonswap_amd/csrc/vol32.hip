@@ -368,11 +368,26 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
             constexpr int NG = SPLIT ? 27 : 9;
             h8_t fa[4], fb[4];
             h8_t wa[SPLIT ? 3 : 1][2], wb[SPLIT ? 3 : 1][2];           // W_lo fragments of a group (pass 1)
+            // group sequence.  Plain: 9 (kd, kh) groups.  Split precision (the halo kernel's chunk order): three passes of 9
+            // groups - W_hi x_hi, W_lo x_hi, W_hi x_lo.  Merged order (-DV32_MERGE): (W_hi x_hi, W_lo x_hi) alternate per group on the SAME four activation
+            // fragments, then the W_hi x_lo pass - 126 instead of 162 LDS reads per step; the pass that streams W_lo from LDS drops from 10 to
+            // 6 reads per 12 MFMAs.  Another (fixed) summation order per output element than conv_halo's hilo kernel: equal to ~1e-7.
+#ifdef V32_MERGE         /* A/B switch: measured 467.7 vs 467.2 frames/s (profiles/r03_l_ab.txt) - not worth another summation order */
+            constexpr bool MERGE = SPLIT;
+#else
+            constexpr bool MERGE = false;
+#endif
+            auto g_pass = [](int G2) { return MERGE ? (G2 < 18 ? (G2 & 1) : 2) : G2 / 9; };
+            auto g_idx = [](int G2) { return MERGE ? (G2 < 18 ? (G2 >> 1) : G2 - 18) : G2 % 9; };
+            auto g_buf = [](int G2) { return MERGE ? (G2 < 18 ? ((G2 >> 1) & 1) : ((G2 - 17) & 1)) : (G2 & 1); };
+            auto g_newb = [](int G2) { return MERGE ? !(G2 < 18 && (G2 & 1)) : true; };
             auto rd = [&](h8_t (&f)[4], h8_t (&wl2)[SPLIT ? 3 : 1][2], int G2) {      // G2: compile-time after unrolling
-                const int pass = G2 / 9, g = G2 % 9, kd = g / 3, kh = g % 3;
+                const int pass = g_pass(G2), g = g_idx(G2), kd = g / 3, kh = g % 3;
                 const int img = (SPLIT && pass == 2) ? IMG : 0;
+                if (g_newb(G2)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) f[i] = *(const h8_t*)(smem + rb[kh] + img + i * V_CS + kd * 16);
+                    for (int i = 0; i < 4; ++i) f[i] = *(const h8_t*)(smem + rb[kh] + img + i * V_CS + kd * 16);
+                }
                 if constexpr (SPLIT) {
                     if (pass == 1) {
 #pragma unroll
@@ -385,13 +400,15 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
             rd(fa, wa, 0);
 #pragma unroll
             for (int G2 = 0; G2 < NG; ++G2) {
-                h8_t (&cur)[4] = (G2 & 1) ? fb : fa;
-                h8_t (&nxt)[4] = (G2 & 1) ? fa : fb;
+                h8_t (&cur)[4] = g_buf(G2) ? fb : fa;
                 h8_t (&wcur)[SPLIT ? 3 : 1][2] = (G2 & 1) ? wb : wa;
                 h8_t (&wnxt)[SPLIT ? 3 : 1][2] = (G2 & 1) ? wa : wb;
-                if (G2 + 1 < NG) rd(nxt, wnxt, G2 + 1);
+                if (G2 + 1 < NG) {
+                    h8_t (&nxt)[4] = g_buf(G2 + 1) ? fb : fa;
+                    rd(nxt, wnxt, G2 + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                const int pass = G2 / 9, g = G2 % 9;
+                const int pass = g_pass(G2), g = g_idx(G2);
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
