@@ -320,7 +320,11 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps;
     }
     // the 3x3x3 32 -> 32 convolutions of the feature volume run on their own kernel (vol32.hip; CANONSWAP_VOL32=0: A/B knob, conv_halo)
-    if (vol32_enabled() && vol32_supported(c.p)) {
+    // (below three frames the strips of a launch cover a quarter of the CUs or less: the plain convs - bit-identical on either kernel - stay
+    // on the halo kernel there, one frame 6.75 -> 6.5 ms; the statistics / transform-staging convs of R always run vol32: their partial
+    // statistics are laid out per kernel, and a frame's bits must not depend on the batch it is part of)
+    static const int vol32_minb = [] { const char* s = getenv("CANONSWAP_VOL32_MINB"); return s ? atoi(s) : 3; }();
+    if (vol32_enabled() && vol32_supported(c.p) && (c.p.N >= vol32_minb || c.p.stat_out || c.p.xf_kind)) {
         c.stat_nblk = vol32_stat_nblk(c.p);
         TRY(e->run(0, st, [&] { return launch_vol32(c.p, st); }, c.name, fl));
         return amax_after(e, c, st);
@@ -433,7 +437,8 @@ bool vol32_fused_on() { static const bool on = [] { const char* s = getenv("CANO
 int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Affine* final_post, int final_act, hipStream_t st)
 {
     // util.py:94-102; a = relu(bn1(x)) is already in va[0]; x (fp32 residual stream) in vs[*cur]
-    if (vol32_fused_on()) {
+    static const int fused_minb = [] { const char* s = getenv("CANONSWAP_VOL32_MINB"); return s ? atoi(s) : 3; }();
+    if (vol32_fused_on() && B >= fused_minb) {
         // block i reads a from va[i & 1] and leaves the next block's a in va[(i + 1) & 1] (a neighbouring workgroup still reads the halo
         // columns of the input while this one stores): six blocks end in va[0] again
         for (int i = 0; i < 6; ++i) {

@@ -1,13 +1,20 @@
 #!/bin/bash
-# GPU box: the round's measurement set -> gpurun_out/$1/ (bench line, rocprofv3 kernel stats of the same command, PMC HBM passes)
+# GPU box: the round's measurement set -> gpurun_out/$1/ (bench line, rocprofv3 kernel stats of the same command, PMC HBM / MFMA passes,
+# per-kernel PMC summary, hbm_traffic.json for bench.py's roofline.traffic, rocprof <-> HIP-event reconciliation)
 TAG=${1:-rXX}; OUT=/root/repo/gpurun_out/$TAG; mkdir -p $OUT
 cd /root/repo
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -1 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python /root/repo/bench.py --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python /root/repo/bench.py --no-cpu-baseline --no-fixed-job > $OUT/bench_profiled.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o pmc --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o pmc --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fixed-job > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA -o pmc --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_MFMA.json 2> $OUT/pmc_MFMA.err
-ls -la $OUT $OUT/stats | head -40
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA -o pmc --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fixed-job > $OUT/pmc_MFMA.json 2> $OUT/pmc_MFMA.err
+cd /root/repo
+python tools/summarize_pmc.py $OUT > $OUT/pmc_summary.csv 2> $OUT/summarize.err
+python tools/summarize_pmc.py $OUT 32 $OUT/hbm_traffic.json 2>> $OUT/summarize.err
+python tools/reconcile_profile.py $(ls $OUT/stats/*kernel_stats.csv | head -1) $OUT/bench_profiled.json 43 > $OUT/reconcile.txt 2>> $OUT/summarize.err
+cat $OUT/reconcile.txt | head -8; cat $OUT/hbm_traffic.json
+# keep the merge-back under the gpurun limit: the raw counter dumps are large
+rm -rf $OUT/pmc_FETCH_SIZE/*.db $OUT/pmc_WRITE_SIZE/*.db $OUT/pmc_MFMA/*.db $OUT/stats/*.db 2>/dev/null
 du -sh $OUT

@@ -39,16 +39,28 @@ def main(root):
         print(f"\"{k}\",{nm[k]},{us:.1f},{fk:.1f},{fk * 2 / 1024:.1f},{wk:.1f},{busy / gui if gui else 0:.3f},{gui / (us * 1e3) if us else 0:.2f}")
 
 
+CONV_KERNELS = ("conv_halo_kernel", "vol32_kernel", "vol32_fused_kernel")
+WARP_KERNELS = ("dm_softmax_warp_kernel", "grid_sample_kernel")
+
+
 def traffic_json(root, batch, out_path):
-    """Launch-weighted HBM bytes per convolution launch (FETCH_SIZE x2-corrected + WRITE_SIZE raw) for bench.py's roofline.traffic."""
+    """Launch-weighted HBM bytes per convolution launch and per warp launch (FETCH_SIZE x2-corrected + WRITE_SIZE raw) for bench.py's
+    roofline.traffic / warp_roofline.traffic."""
     import json
     f, nf, _ = load(f"{root}/pmc_FETCH_SIZE/pmc_counter_collection.csv")
     w, nw, _ = load(f"{root}/pmc_WRITE_SIZE/pmc_counter_collection.csv")
-    conv = [k for k in f if "conv_halo_kernel" in k or "conv_igemm_kernel" in k]
-    n = sum(nf[k] for k in conv)
-    fb = sum(f[k]["FETCH_SIZE"] for k in conv) * 2 * 1024 / n
-    wb = sum(w[k]["WRITE_SIZE"] for k in conv) * 1024 / max(sum(nw[k] for k in conv), 1)
-    json.dump({"batch": batch, "conv_launches_counted": n, "fetch_bytes_per_conv_launch_x2": round(fb), "write_bytes_per_conv_launch_raw": round(wb),
+
+    def per_launch(names):
+        ks = [k for k in f if any(n in k for n in names)]
+        n = sum(nf[k] for k in ks)
+        fb = sum(f[k]["FETCH_SIZE"] for k in ks) * 2 * 1024 / max(n, 1)
+        wb = sum(w[k]["WRITE_SIZE"] for k in ks) * 1024 / max(sum(nw[k] for k in ks), 1)
+        return n, round(fb), round(wb)
+
+    n, fb, wb = per_launch(CONV_KERNELS)
+    nwp, wfb, wwb = per_launch(WARP_KERNELS)
+    json.dump({"batch": batch, "conv_launches_counted": n, "fetch_bytes_per_conv_launch_x2": fb, "write_bytes_per_conv_launch_raw": wb,
+               "warp_launches_counted": nwp, "warp_fetch_bytes_per_launch_x2": wfb, "warp_write_bytes_per_launch_raw": wwb,
                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1; "
                          "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-byte requests at 64 bytes), WRITE_SIZE uncalibrated"},
               open(out_path, "w"), indent=1)
