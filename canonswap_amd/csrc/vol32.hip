@@ -407,7 +407,9 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                     h8_t (&nxt)[4] = g_buf(G2 + 1) ? fb : fa;
                     rd(nxt, wnxt, G2 + 1);
                 }
+#ifdef V32_NOINTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 const int pass = g_pass(G2), g = g_idx(G2);
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw)
@@ -418,6 +420,18 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                             const h8_t a = (SPLIT && pass == 1) ? wcur[SPLIT ? kw : 0][ci] : wr[g * 3 + kw][ci];
                             acc[c][ci] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, cur[kw + c], acc[c][ci], 0, 0, 0);
                         }
+#ifndef V32_NOINTERLEAVE
+                // the LDS reads of the next group go out BETWEEN this group's 12 MFMAs (one wave per SIMD: a block of reads ahead of the
+                // MFMAs is 30 - 80 cycles of idle matrix pipe per group): one read per MFMA until they are out, then the remaining MFMAs
+                if (G2 + 1 < NG) {
+                    const int nrd = (g_newb(G2 + 1) ? 4 : 0) + ((SPLIT && g_pass(G2 + 1) == 1) ? 6 : 0);
+#pragma unroll
+                    for (int i = 0; i < (nrd < 11 ? nrd : 11); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one DS read
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef V32_NOSPREAD
                 // the step's memory instructions (DMA pieces of row h + K first, then the stores of row h - 1: the order the counted wait

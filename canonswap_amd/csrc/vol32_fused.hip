@@ -216,11 +216,17 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
 #pragma unroll
                             for (int i = 0; i < 7; ++i) nxt[i] = *(const h8_t*)(smem + rb[kh] + i * F_CS + kd * 16);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                             for (int c = 0; c < 5; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g * 3 + kw], cur[kw + c], acc[c], 0, 0, 0);
+                        if (g + 1 < 9) {     // the 7 LDS reads of the next group interleaved with this group's MFMAs, two MFMAs per read
+#pragma unroll
+                            for (int i = 0; i < 7; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     FTL(2);
@@ -273,11 +279,17 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
 #pragma unroll
                             for (int i = 0; i < 6; ++i) nxt[i] = *(const h8_t*)(himg + rb[kh] + i * F_CS + kd * 16);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc2[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g * 3 + kw], cur[kw + c], acc2[c], 0, 0, 0);
+                        if (g + 1 < 9) {     // the 6 LDS reads of the next group interleaved with this group's MFMAs, two MFMAs per read
+#pragma unroll
+                            for (int i = 0; i < 6; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     pend = true; hprev = ro;
