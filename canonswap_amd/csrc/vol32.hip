@@ -238,21 +238,28 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 xsh[r] = gn_shift(mean, xsc[r], p.xf_beta[c]);
             }
         }
-        auto xf_ok = [&](int r, int it) -> bool {
-            const int idx = it * 256 + tid, col = idx >> 6;
-            return idx < V_NC * 64 && (unsigned)r < (unsigned)p.H && r <= h1 && (unsigned)(w0 - 1 + col) < (unsigned)p.W;
-        };
-        auto xf_load = [&](int r, int it) {       // raw piece it of row r -> registers
-            if constexpr (XF != 0) {
+        // per-item constants of a piece: element offset inside the sample's row (the three fp32 volumes share their strides: the launcher
+        // checks), LDS byte offset inside a ring slot, validity of its column, ownership of its column (write-back)
+        int xoff[XF ? 3 : 1]; bool xcok[XF ? 3 : 1];
+        if constexpr (XF != 0) {
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
                 const int idx = it * 256 + tid, col = idx >> 6, d = (idx >> 2) & 15;
+                xoff[it] = n * p.xy_sN + (w0 - 1 + col) * p.xy_sW + d * 32 + xq * 8;
+                xcok[it] = idx < V_NC * 64 && (unsigned)(w0 - 1 + col) < (unsigned)p.W;
+            }
+        }
+        auto xf_load = [&](int r, int it) {       // raw piece it of row r -> registers (zeros outside the volume)
+            if constexpr (XF != 0) {
                 xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
                 if constexpr (XF == 2) { xs[it][0] = xr[it][0]; xs[it][1] = xr[it][0]; }
-                if (xf_ok(r, it)) {
-                    const float* y = p.xf_y + ((long)n * p.xy_sN + (long)r * p.xy_sH + (long)(w0 - 1 + col) * p.xy_sW + d * 32 + xq * 8);
+                if (xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1) {
+                    const unsigned o = (unsigned)(xoff[it] + r * p.xy_sH);
+                    const float* y = p.xf_y + o;
                     xr[it][0] = *(const float4*)y; xr[it][1] = *(const float4*)(y + 4);
                     if constexpr (XF == 2) {
                         if (p.xf_res) {
-                            const float* x = p.xf_res + ((long)n * p.xr_sN + (long)r * p.xr_sH + (long)(w0 - 1 + col) * p.xr_sW + d * 32 + xq * 8);
+                            const float* x = p.xf_res + o;
                             xs[it][0] = *(const float4*)x; xs[it][1] = *(const float4*)(x + 4);
                         }
                     }
@@ -261,9 +268,9 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
         };
         auto xf_write = [&](int r, int slot, int it) {     // registers -> transform -> [hi | lo] images of ring slot `slot`
             if constexpr (XF != 0) {
-                const int idx = it * 256 + tid, col = idx >> 6, d = (idx >> 2) & 15;
+                const int idx = it * 256 + tid;
                 if (idx < V_NC * 64) {
-                    const bool ok = xf_ok(r, it);
+                    const bool ok = xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1;
                     float a[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -275,12 +282,13 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                     h8_t hi, lo;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) { hi[k] = (half_t)a[k]; lo[k] = (half_t)(a[k] - (float)hi[k]); }
-                    unsigned char* dst = smem + xq * QS + slot * V_RS + col * V_CS + (d + 1) * 16;
+                    unsigned char* dst = smem + xq * QS + (idx >> 6) * V_CS + (((idx >> 2) & 15) + 1) * 16 + slot * V_RS;
                     *(h8_t*)dst = hi; *(h8_t*)(dst + IMG) = lo;
                     if constexpr (XF == 2) {
                         // the transformed tensor is the new residual stream: every strip writes the rows and columns it owns
+                        const int col = idx >> 6;
                         if (p.xf_out && ok && col >= 1 && col <= V_TW && r >= h0 && r < h1) {
-                            float* o = p.xf_out + ((long)n * p.xo_sN + (long)r * p.xo_sH + (long)(w0 - 1 + col) * p.xo_sW + d * 32 + xq * 8);
+                            float* o = p.xf_out + (unsigned)(xoff[it] + r * p.xy_sH);
                             *(float4*)o = make_float4(a[0], a[1], a[2], a[3]); *(float4*)(o + 4) = make_float4(a[4], a[5], a[6], a[7]);
                         }
                     }
@@ -403,6 +411,11 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 h8_t (&cur)[4] = g_buf(G2) ? fb : fa;
                 h8_t (&wcur)[SPLIT ? 3 : 1][2] = (G2 & 1) ? wb : wa;
                 h8_t (&wnxt)[SPLIT ? 3 : 1][2] = (G2 & 1) ? wa : wb;
+#ifndef V32_XF_NOIL
+                // transform staging: the conversion of piece G2 / 2 of row h + 2 (VALU + two ds_writes) shares the scheduling region of this
+                // group's MFMAs and is spread between them (below)
+                if constexpr (XF != 0) { if (G2 < 6 && (G2 & 1) == 0) xf_write(h + 2, sk, G2 >> 1); }
+#endif
                 if (G2 + 1 < NG) {
                     h8_t (&nxt)[4] = g_buf(G2 + 1) ? fb : fa;
                     rd(nxt, wnxt, G2 + 1);
@@ -425,10 +438,16 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 // MFMAs is 30 - 80 cycles of idle matrix pipe per group): one read per MFMA until they are out, then the remaining MFMAs
                 if (G2 + 1 < NG) {
                     const int nrd = (g_newb(G2 + 1) ? 4 : 0) + ((SPLIT && g_pass(G2 + 1) == 1) ? 6 : 0);
+#ifndef V32_XF_NOIL
+                    const bool conv_here = XF != 0 && G2 < 6 && (G2 & 1) == 0;
+#else
+                    const bool conv_here = false;
+#endif
 #pragma unroll
-                    for (int i = 0; i < (nrd < 11 ? nrd : 11); ++i) {
+                    for (int i = 0; i < 11; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one DS read
+                        if (i < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one DS read
+                        if (conv_here) __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);    // a dozen VALU instructions of the conversion
                     }
                 }
 #endif
@@ -452,7 +471,9 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                     // transform staging: row h + 2 (in registers since last step) -> slot sk after groups 0 / 2 / 4, the loads of row h + 3 after
                     // groups 6 / 8 / 10, then the stores of row h - 1: every wait the compiler places at a conversion finds loads and stores that
                     // are most of a step old
+#ifdef V32_XF_NOIL
                     if (G2 < 6 && (G2 & 1) == 0) xf_write(h + 2, sk, G2 >> 1);
+#endif
                     if (G2 >= 6 && G2 < 12 && (G2 & 1) == 0) xf_load(h + 3, (G2 - 6) >> 1);
                     if (G2 >= 12 && G2 < 12 + NS && have) store_piece(G2 - 12);
                     __builtin_amdgcn_sched_barrier(0);
@@ -597,6 +618,8 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     k.xf_out = (float*)p.xf_out.p; k.xo_sN = (int)p.xf_out.sN; k.xo_sH = (int)p.xf_out.sH; k.xo_sW = (int)p.xf_out.sW;
     k.xf_stats = p.xf_stats; k.xf_gamma = p.xf_gamma; k.xf_beta = p.xf_beta; k.xf_slope = p.xf_slope;
     if (p.xf_kind) {
+        auto same = [&](const TDesc& t) { return !t.p || (t.sN == p.xf_y.sN && t.sH == p.xf_y.sH && t.sW == p.xf_y.sW); };
+        if (!same(p.xf_res) || !same(p.xf_out)) { cs_set_error("vol32: the transform-staging volumes must share their strides"); return -1; }
         const long lim = 1L << 31;
         auto span = [&](const TDesc& t) { return (long)(p.N - 1) * t.sN + (long)(p.H - 1) * t.sH + (long)(p.W - 1) * t.sW + 512; };
         if (span(p.xf_y) >= lim || (p.xf_res.p && span(p.xf_res) >= lim) || (p.xf_out.p && span(p.xf_out) >= lim)) {

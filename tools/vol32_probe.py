@@ -77,6 +77,20 @@ def main():
     if a.cfg == 30:
         cases["fused ResBlock3d (c1 + c2)"] = fused
     FPH = ["startup", "prologue", "compute", "memory instr", "epilogue", "lgkm wait", "vm wait", "barrier", "step head", "tail"]
+    # transform staging (GroupNorm apply + residual + write-back inside the staging of the split-precision conv)
+    yv = vol(B, dtype=torch.float32, rnd=r); rv = vol(B, dtype=torch.float32, rnd=r)
+    stats = torch.stack([torch.zeros(B, 32), torch.ones(B, 32)], dim=2).contiguous().to(DEV)
+    gam = torch.ones(32, device=DEV); bet = torch.zeros(32, device=DEV)
+    if a.cfg == 30:
+        sto = torch.empty(B * 256 * 64, dtype=torch.float32, device=DEV)
+        xo = vol(B, dtype=torch.float32)
+        cases["split + stats, XF kind 1"] = lambda: ops.conv(x2, w3, 32, 32, (3, 3, 3), cin=96, bias=b, out0=vol(B, dtype=torch.float32), cfg=30, hilo=True,
+                                                              stat_out=sto, xf=dict(kind=1, y=yv))
+        cases["split + stats, XF kind 2"] = lambda: ops.conv(x2, w3, 32, 32, (3, 3, 3), cin=96, bias=b, out0=vol(B, dtype=torch.float32), cfg=30, hilo=True,
+                                                              stat_out=sto, xf=dict(kind=2, y=yv, stats=stats, gamma=gam, beta=bet, slope=0.01))
+        cases["split + stats, XF kind 2 + res + write-back"] = lambda: ops.conv(x2, w3, 32, 32, (3, 3, 3), cin=96, bias=b, out0=vol(B, dtype=torch.float32),
+                                                                                cfg=30, hilo=True, stat_out=sto,
+                                                                                xf=dict(kind=2, y=yv, stats=stats, gamma=gam, beta=bet, slope=0.01, res=rv, out=xo))
     gfl = 2 * 27 * 32 * 32 * B * 65536 / 1e9
     for name, fn in cases.items():
         for _ in range(3):
@@ -90,7 +104,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.reps
-        print(f"{name:28s} {us:8.1f} us/launch  {gfl / us / 1e3:7.1f} TFLOP/s algorithmic ({gfl / us / 1e3 / 2500:.3f} of peak)")
+        print(f"{name:44s} {us:8.1f} us/launch  {gfl / us * 1e-3:7.1f} TFLOP/s algorithmic ({gfl / us * 1e-3 / 2500:.3f} of peak)")
         if tlf is not None and name.startswith("fused"):
             tlf.zero_()
             fn()
