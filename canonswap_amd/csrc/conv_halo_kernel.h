@@ -371,33 +371,56 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             h8_t afA[HA > 0 ? HA : 1], afB[WPX - HA];
 #pragma unroll
             for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + ab_of(pi, 0) + toff_of(0));
+            // Interleaved issue (one wave per SIMD kernels: the 256-position tiles of the hourglass tail, the mask conv and the first encoder
+            // block): the LDS reads of the other half and the reload of the weight slot the PREVIOUS step used go out between the MFMAs of a
+            // half instead of as a block ahead of them.  A block of 4 ds_reads + 5 global loads is 50 - 100 cycles of idle matrix pipe per
+            // 20 MFMAs when no other wave shares the SIMD: tail 2.25 -> 2.15 ms, mask 3.46 -> 3.33 ms per 32 frames, +1 % on the step
+            // (profiles/r03_n_ab_ilv.txt; -DCS_NO_ILV is the A/B switch, -DCS_ILV_ALL extends it to every static kernel)
+#if defined(CS_NO_ILV)
+            constexpr bool ILV = false;
+#elif defined(CS_ILV_ALL)
+            constexpr bool ILV = (WPX >= 2);
+#else
+            constexpr bool ILV = (WPX == 8 && WVP == 2);
+#endif
 #pragma unroll
             for (int st = 0; st < NSC; ++st) {
                 const int toff = toff_of(st);
 #pragma unroll
                 for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + ab_of(pi, st) + toff);
-                __builtin_amdgcn_sched_barrier(0);
+                if (ILV && st >= 1 && st - 1 + PFS < NSC) wload_at(wr[(st - 1) % PFS], cc, st - 1 + PFS);
+                if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
 #pragma unroll
                     for (int pi = 0; pi < HA; ++pi)
                         acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afA[pi],
                                                                              acc[ci][pi], 0, 0, 0);
+                if (ILV) {
+#pragma unroll
+                    for (int i = 0; i < WPX - HA; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (st + 1 < NSC) {
 #pragma unroll
                     for (int pi = 0; pi < HA; ++pi)
                         afA[pi] = *(const h8_t*)(hb + ab_of(pi, st + 1) + toff_of(st + 1));
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
 #pragma unroll
                     for (int pi = HA; pi < WPX; ++pi)
                         acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afB[pi - HA],
                                                                              acc[ci][pi], 0, 0, 0);
+                if (ILV) {
+#pragma unroll
+                    for (int i = 0; i < HA; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + PFS < NSC) wload_at(wr[st % PFS], cc, st + PFS);
+                if (!ILV && st + PFS < NSC) wload_at(wr[st % PFS], cc, st + PFS);
             }
         };
         // the ragged chunk is peeled off the loop (inside it, the two bodies together cost the 160-wide kernels 500-650 bytes of scratch)

@@ -170,26 +170,42 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
         bool pend = false;
         int hprev = 0;
         int sa = 0;                              // a-ring slot of row t - 1 (conv1 at step t reads a rows t - 1, t, t + 1)
-        auto finish_row = [&]() {                // conv2: epilogue + stores of row hprev (conv_epilogue.h formulas, same order of operations)
+        float ov[4][4]; ep_u2_t ou[4];           // conv2: finished values of row hrow, stored one instruction per MFMA group
+        int hrow = 0;
+        auto finish_math = [&]() {               // conv2: epilogue arithmetic of row hprev (conv_epilogue.h formulas, same order of operations)
             f4_t rr[4];                          // residual, staged by the conv1 lane of the same index
             const int xsl = ((hprev % F_RRING) + F_RRING) % F_RRING;
 #pragma unroll
             for (int c = 0; c < 4; ++c) rr[c] = *(const f4_t*)(rring + xsl * F_RSLOT + (wave & 3) * 4096 + c * 1024 + lane * 16);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                h4_t uu; float ov[4];
+                h4_t uu;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc2[c][r] + bias_v[r];
                     v = lin_act(v, 1.f);
                     v += rr[c][r];
-                    ov[r] = v;
+                    ov[c][r] = v;
                     const float a2 = v * s2_v[r] + t2_v[r];
                     uu[r] = (half_t)lin_act(a2, p.sl1);
                 }
-                *(float4*)(p.out0 + (nb_o0 + (unsigned)(hprev * p.o0_sH + c * p.o0_sW) + lane_el)) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-                *(ep_u2_t*)(p.out1 + (nb_o1 + (unsigned)(hprev * p.o1_sH + c * p.o1_sW) + lane_el)) = __builtin_bit_cast(ep_u2_t, uu);
+                ou[c] = __builtin_bit_cast(ep_u2_t, uu);
             }
+            hrow = hprev;
+        };
+        auto store_k = [&](int k) {              // store k (0 .. 7) of row hrow
+            asm volatile("" ::: "memory");
+            const int c = k >> 1;
+            if ((k & 1) == 0) *(float4*)(p.out0 + (nb_o0 + (unsigned)(hrow * p.o0_sH + c * p.o0_sW) + lane_el)) = make_float4(ov[c][0], ov[c][1], ov[c][2], ov[c][3]);
+            else *(ep_u2_t*)(p.out1 + (nb_o1 + (unsigned)(hrow * p.o1_sH + c * p.o1_sW) + lane_el)) = ou[c];
+            asm volatile("" ::: "memory");
+        };
+        auto dma_k = [&](int tt, int k) {        // conv1: DMA instruction k (0 .. 7) of step tt: a row tt + 3 into the slot row tt - 2 left, residual row tt - 1
+            asm volatile("" ::: "memory");
+            int sk = sa + F_KA + 2; sk -= sk >= F_ARING ? F_ARING : 0;
+            if (k < 4) stage_a(tt + 3, sk, k);
+            else stage_x(tt - 1, (((tt - 1) % F_RRING) + F_RRING) % F_RRING, k - 4);
+            asm volatile("" ::: "memory");
         };
         // step t: conv1 -> h row t (rows h0 - 1 .. h1), conv2 -> output row t - 2 (rows h0 .. h1 - 1)
         for (int tt = h0 - 1; tt <= h1 + 1; ++tt) {
@@ -228,6 +244,9 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
+#ifdef F_SPREAD
+                        if (g < 8) { dma_k(tt, g); __builtin_amdgcn_sched_barrier(0); }
+#endif
                     }
                     FTL(2);
                     // h = relu(conv1 + b1) as fp16 (what the two-launch path stores); outside the volume h is conv2's zero padding
@@ -243,22 +262,32 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
                     }
                     FTL(4);
                 }
+#ifdef F_SPREAD
+                if (!c1_on) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dma_k(tt, k);
+                }
+                // the 8 DMA instructions of the LAST step must have landed (rows / residuals the next step reads); this step's may stay in flight
+                f_wait_vm<8>();
+                FTL(6);
+#else
                 // the DMA instructions issued at the end of the last step are a whole step old: everything this wave has in flight may drain
                 f_wait_vm<0>();
                 FTL(6);
-                // a row tt + 3 into the slot row tt - 2 left (read last in step tt - 1), residual row tt - 1 (consumed at the head of step tt + 2)
-                {
-                    int sk = sa + F_KA + 2; sk -= sk >= F_ARING ? F_ARING : 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) stage_a(tt + 3, sk, j);
-                    const int xsl = (((tt - 1) % F_RRING) + F_RRING) % F_RRING;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) stage_x(tt - 1, xsl, c);
-                }
+                for (int k = 0; k < 8; ++k) dma_k(tt, k);
                 FTL(3);
+#endif
             } else {
                 // ---------------- conv2: finish output row hprev, then accumulate output row tt - 2 from h rows tt - 3 .. tt - 1
-                if (pend) { finish_row(); pend = false; }
+                const bool st_on = pend;
+                if (pend) { finish_math(); pend = false; }
+#ifndef F_SPREAD
+                if (st_on) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) store_k(k);
+                }
+#endif
                 FTL(3);
                 if (c2_on) {
                     const int ro = tt - 2;
@@ -291,10 +320,19 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
+#ifdef F_SPREAD
+                        if (g < 8 && st_on) { store_k(g); __builtin_amdgcn_sched_barrier(0); }
+#endif
                     }
                     pend = true; hprev = ro;
                     FTL(2);
                 }
+#ifdef F_SPREAD
+                else if (st_on) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) store_k(k);
+                }
+#endif
             }
             sa = sa + 1 == F_ARING ? 0 : sa + 1;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS traffic (the h row) is done
@@ -306,7 +344,11 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
             tl_steps += 1;
 #endif
         }
-        if (role && pend) finish_row();
+        if (role && pend) {
+            finish_math();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) store_k(k);
+        }
         __syncthreads();                         // the next item's prologue overwrites the rings
         FTL(9);
     }
