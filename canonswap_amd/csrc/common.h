@@ -104,6 +104,11 @@ struct ConvParams {
     //           mean / rstd per (sample, channel) from xf_stats [N][32][2]; with xf_out the interior of a is also written back: the new
     //           residual stream)
     // and split into [hi | lo] fp16 on the way into LDS (the conv must be a split-precision one: hilo).
+    // conv_halo, the kw-split mask conv only (7x7x1 taps, 7 x 22 = 154 output channels (kw, c), 2 x 8 x 16 tiles): instead of storing the 154
+    // partials of every position (out0), the workgroup adds, through LDS, the partials its two columns contribute to the same output column
+    // and stores 8 logit vectors per tile row: kw_out[((n * D + d) * H + h) * (W / 2) + tile][j][22], j <-> output column w0 - 3 + j
+    // (dense_motion.py:88: logit(w) = sum_kw part[w + kw - 3][kw]).  45 % fewer bytes on both sides of the hand-over to the softmax.
+    float* kw_out;
     int xf_kind;
     TDesc xf_y, xf_res, xf_out;
     const float* xf_stats; const float* xf_gamma; const float* xf_beta;
@@ -166,9 +171,9 @@ int launch_dm_compress(const float* f, const float* w, const float* b, half_t* c
 int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, half_t* out, int out_stride, int N, int D,
                      int H, int W, hipStream_t st);
 int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
-                      int N, int D, int H, int W, hipStream_t st);
+                      int N, int D, int H, int W, hipStream_t st, int compact = 0);
 int launch_dm_softmax_warp(const float* part, const float* bias, const float* kp_d, const float* kp_s, const float* in, float* out32,
-                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st);
+                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact = 0);
 int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
 int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);
 int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st);

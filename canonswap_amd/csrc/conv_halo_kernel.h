@@ -531,6 +531,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // sigmoid / GELU epilogues exist in: the pixel-shuffle kernel (conv_img), the 16-channel tiles (T's mask conv), the 1x1 kernels
     // (the motion extractor's linear layers) and the dynamic-shape fallbacks (small maps of the same layers)
     constexpr bool EP_HEAVY = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
+    constexpr bool KWSUM = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && ST == 8;      // the kw-split mask conv (ConvParams::kw_out)
     TL_STAMP(3);
     if constexpr (!SK) {
         if (p.sk_out) {      // split-K: this workgroup's partial sums, fp32, [split][position][channel]; finished by splitk_finish_kernel
@@ -547,6 +548,50 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
                     *(f4_t*)(p.sk_out + ((long)blockIdx.z * mtot + pos) * p.Cout_pad + ep_chan(EP_PAIR, 1, n0 + wch * WCH * 16, ci, l4)) = acc[ci][pi];
+            }
+        } else if (KWSUM && p.kw_out) {
+            // ---- mask conv: in-tile sum over kw (ConvParams::kw_out).  Tile 2 (w) x 8 (h) x 16 (d); a 16-position block of a wave is the
+            // depth slice d = wpx * 8 + pi with l15p = (h << 1) | w'.  Per depth slice the two channel waves of a position half lay their
+            // 160 channels into LDS ([16 positions][160] fp32), then its 128 threads add, for each of the 8 output columns j (w0 - 3 + j)
+            // the tile touches, P[w' = 0][kw = 6 - j] + P[w' = 1][kw = 7 - j] and store 8 x 22 logits per (d, h) - one 704-byte run.
+            if constexpr (KWSUM) {
+                __syncthreads();                               // every wave has left the halo: the LDS is free
+                constexpr int ZERO = 16 * 160;                 // a zero float behind the image of a position half: the missing term at j = 0 / 7
+                float* buf = (float*)smem + wpx * (16 * 160 + 4);
+                const int th128 = wch * 64 + lane;
+                if (th128 == 0) buf[ZERO] = 0.f;
+                // every thread finishes 3 float4 (12 logits) of the 8 (h) x 176 (j, c) block of a depth slice; the LDS offsets of their two
+                // terms and the global offset do not depend on the slice
+                int offA[12], offB[12], goff[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int fi = q * 128 + th128;            // float4 index, 352 per slice
+                    goff[q] = (fi * 4 / 176) * (p.nTW * 176) + (fi * 4) % 176;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = fi * 4 + e, c = idx % 22, j = (idx / 22) & 7, h = (idx / 176) & 7;
+                        offA[q * 4 + e] = j <= 6 ? (h << 1) * 160 + (6 - j) * 22 + c : ZERO;
+                        offB[q * 4 + e] = j >= 1 ? ((h << 1) | 1) * 160 + (7 - j) * 22 + c : ZERO;
+                    }
+                }
+                float* const gbase = p.kw_out + ((((long)tn * p.D + (td << lgTD) + wpx * WPX) * p.H + (th << lgTH)) * p.nTW + tw) * 176;
+                const long gslice = (long)p.H * p.nTW * 176;  // one depth slice further
+#pragma unroll
+                for (int pi = 0; pi < WPX; ++pi) {             // unrolled: the accumulators are registers, no dynamic index
+#pragma unroll
+                    for (int ci = 0; ci < WCH; ++ci) *(f4_t*)(buf + l15p * 160 + wch * (WCH * 16) + ci * 16 + l4 * 4) = acc[ci][pi];
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        if (q * 128 + th128 < 352) {
+                            f4_t v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = buf[offA[q * 4 + e]] + buf[offB[q * 4 + e]];
+                            *(f4_t*)(gbase + pi * gslice + goff[q]) = v;
+                        }
+                    }
+                    __syncthreads();
+                }
             }
         } else {
         constexpr int EP_WPX = WPX;
@@ -627,6 +672,13 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         return -1;
     }
     if (p.inD != p.D) { cs_set_error("conv_halo: depth-collapsing convs are not supported"); return -1; }
+    if (p.kw_out) {
+        constexpr bool kwsum = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && ST == 8;
+        if (!kwsum || p.Cout_pad != 160 || p.lgTW != 1 || p.lgTH != 3 || p.lgTD != 4 || p.sk_out || p.W % 2 || p.nTN != p.N) {
+            cs_set_error("conv_halo: kw_out is the mask conv's epilogue (7x7x1 taps, 160 packed channels, 2x8x16 tiles of one sample)");
+            return -1;
+        }
+    }
     const int lgS = p.lgTW + p.lgTH + p.lgTD;
     if ((1 << lgS) > BM) { cs_set_error("conv_halo: spatial tile exceeds BM"); return -1; }
     if (MODE == MODE_SPADE && (1 << lgS) != BM) { cs_set_error("conv_halo: SPADE launches must tile within one sample"); return -1; }

@@ -559,16 +559,22 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
+    // ... or, on the 256-position tiles (2 x 8 x 16), summed over kw inside the tile as far as the tile reaches: 8 logit vectors per 2 columns
+    // instead of 14 (ConvParams::kw_out; CANONSWAP_MASK_KWSUM=0: A/B knob).  Another, fixed summation order of the 7 partials of a logit.
+    static const bool kwsum_on = [] { const char* s = getenv("CANONSWAP_MASK_KWSUM"); return !s || atoi(s) != 0; }();
+    static const bool wide_tile = getenv("CANONSWAP_MASK_TILE8") != nullptr;
+    const int compact = (kwsum_on && big160() && !wide_tile && !mask_out) ? 1 : 0;
+    if (compact) { m.p.kw_out = e->dm_logits; m.p.out0.p = nullptr; }
     m.hcfg = big160() ? CFG_H_256x160 : CFG_H_128x160;
     {   // no halo along W (KW = 1): a 2x8x8 tile stages 392 halo voxels per 128 positions, 8x8x2 would stage 896
         static const bool wide = getenv("CANONSWAP_MASK_TILE8") != nullptr;
         TRY(go(e, m, st, wide ? 8 : 2, 8));
     }
     if (warp_in && !mask_out && warp_fused()) {
-        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, e->dm_deform, B, FD, FH, FW, st); },
+        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, e->dm_deform, B, FD, FH, FW, st, compact); },
                    "dm_softmax_warp"));
     } else {
-        TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st); }, "dm_softmax"));
+        TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st, compact); }, "dm_softmax"));
         if (warp_in) TRY(e->run(2, st, [&] { return launch_grid_sample(warp_in, e->dm_deform, warp_o32, warp_o16, B, FD, FH, FW, st); }, "grid_sample"));
     }
     // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose

@@ -233,20 +233,28 @@ int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, h
 // (row stride 160 floats). This kernel adds the seven horizontally shifted partials:
 //     logit_c(d,h,w) = bias_c + sum_kw part[(d,h,w+kw-3)][kw*22+c]   (zero padding in w),
 // then softmax and the motion blend. deformation out: fp32 [N][D][H][W][3]; optional mask out [N][22][D][H][W].
-__global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                         const float* __restrict__ kp_d, const float* __restrict__ kp_s,
-                                                         float* __restrict__ deform, float* __restrict__ mask_out, int N, int D, int H, int W)
+// the 22 mask logits of voxel v = (n, d, y, x): bias + the mask conv's partials.  compact 0: part[voxel][kw * 22 + c] of the 7 voxels
+// x - 3 .. x + 3 (ConvParams::out0 of the kw-split conv);  compact 1: the in-tile sums part[((n D + d) H + y) * (W / 2) + T][j][22] of the
+// (up to) four 2-column tiles T whose 8 output columns 2 T - 3 .. 2 T + 4 include x (ConvParams::kw_out), T ascending: a fixed order
+__device__ __forceinline__ void dm_logits(float (&l)[22], const float* __restrict__ part, const float* __restrict__ bias, long v, int x, int W,
+                                          int compact)
 {
-    const long total = (long)N * D * H * W;
-    const long v = (long)blockIdx.x * 256 + threadIdx.x;
-    if (v >= total) return;
-    const int x = v % W; long r = v / W;
-    const int y = r % H; r /= H;
-    const int d = r % D;
-    const int n = r / D;
-    float l[22];
 #pragma unroll
     for (int k = 0; k < 22; ++k) l[k] = bias[k];
+    if (compact) {
+        const long row = (v - x) / 2 * 176;                  // first tile of this (n, d, y) row: (v - x) is the row's first voxel, W / 2 tiles x 176
+        const int T0 = (x >> 1) - 2 + (x & 1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int T = T0 + dt;
+            if ((unsigned)T < (unsigned)(W >> 1)) {
+                const float2* src = (const float2*)(part + row + (long)T * 176 + (x - 2 * T + 3) * 22);
+#pragma unroll
+                for (int j = 0; j < 11; ++j) { const float2 q = src[j]; l[2 * j] += q.x; l[2 * j + 1] += q.y; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int kw = 0; kw < 7; ++kw) {
         const int xx = x + kw - 3;
@@ -256,6 +264,22 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
             for (int j = 0; j < 11; ++j) { const float2 q = src[j]; l[2 * j] += q.x; l[2 * j + 1] += q.y; }
         }
     }
+}
+
+__global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                         const float* __restrict__ kp_d, const float* __restrict__ kp_s,
+                                                         float* __restrict__ deform, float* __restrict__ mask_out, int N, int D, int H, int W,
+                                                         int compact)
+{
+    const long total = (long)N * D * H * W;
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= total) return;
+    const int x = v % W; long r = v / W;
+    const int y = r % H; r /= H;
+    const int d = r % D;
+    const int n = r / D;
+    float l[22];
+    dm_logits(l, part, bias, v, x, W, compact);
     float mx = l[0];
 #pragma unroll
     for (int k = 1; k < 22; ++k) mx = fmaxf(mx, l[k]);
@@ -284,10 +308,11 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
 }
 
 int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
-                      int N, int D, int H, int W, hipStream_t st)
+                      int N, int D, int H, int W, hipStream_t st, int compact)
 {
+    if (compact && (W & 1)) { cs_set_error("dm_softmax: the compact partial layout needs an even width"); return -1; }
     hipLaunchKernelGGL(dm_softmax_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, part, bias, kp_d, kp_s,
-                       deform, mask_out, N, D, H, W);
+                       deform, mask_out, N, D, H, W, compact);
     LAUNCH_CHECK("dm_softmax");
     return 0;
 }
@@ -301,7 +326,7 @@ int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, c
 __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                               const float* __restrict__ kp_d, const float* __restrict__ kp_s,
                                                               const float* __restrict__ in, float* __restrict__ out32, half_t* __restrict__ out16,
-                                                              float* __restrict__ deform, int N, int D, int H, int W)
+                                                              float* __restrict__ deform, int N, int D, int H, int W, int compact)
 {
     __shared__ float defs[256 * 3];
     long blk = blockIdx.x;
@@ -315,17 +340,7 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
         const int d = t >> 4, x = wb * 16 + (t & 15);
         const long v = (((long)n * D + d) * H + y) * W + x;
         float l[22];
-#pragma unroll
-        for (int k = 0; k < 22; ++k) l[k] = bias[k];
-#pragma unroll
-        for (int kw = 0; kw < 7; ++kw) {
-            const int xx = x + kw - 3;
-            if ((unsigned)xx < (unsigned)W) {
-                const float2* src = (const float2*)(part + (v + kw - 3) * 160 + kw * 22);
-#pragma unroll
-                for (int j = 0; j < 11; ++j) { const float2 q = src[j]; l[2 * j] += q.x; l[2 * j + 1] += q.y; }
-            }
-        }
+        dm_logits(l, part, bias, v, x, W, compact);
         float mx = l[0];
 #pragma unroll
         for (int k = 1; k < 22; ++k) mx = fmaxf(mx, l[k]);
@@ -383,11 +398,11 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
 }
 
 int launch_dm_softmax_warp(const float* part, const float* bias, const float* kp_d, const float* kp_s, const float* in, float* out32,
-                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st)
+                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact)
 {
     if (D != 16 || (W & 15)) { cs_set_error("dm_softmax_warp: depth 16 and a width that is a multiple of 16"); return -1; }
     hipLaunchKernelGGL(dm_softmax_warp_kernel, dim3((unsigned)((long)N * H * (W >> 4))), dim3(256), 0, st, part, bias, kp_d, kp_s, in,
-                       out32, out16, deform, N, D, H, W);
+                       out32, out16, deform, N, D, H, W, compact);
     LAUNCH_CHECK("dm_softmax_warp");
     return 0;
 }
