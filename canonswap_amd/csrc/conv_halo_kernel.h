@@ -380,6 +380,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             constexpr bool ILV = false;
 #elif defined(CS_ILV_ALL)
             constexpr bool ILV = (WPX >= 2);
+#elif defined(CS_ILV_128)
+            constexpr bool ILV = (WPX == 8 && WVP == 2) || (WPX == 8 && WCH == 2 && WVP == 1);
 #else
             constexpr bool ILV = (WPX == 8 && WVP == 2);
 #endif
