@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
         // the output row it accumulated in the step before (its accumulators wait across the barrier) and then runs its MFMAs, the conv1 wave
         // opens with its MFMAs and closes with its epilogue (h row into LDS) and the step's 8 DMA instructions.  In lock step (both MFMA
         // phases, then both epilogues) the matrix pipe idled through the epilogues and memory instructions of both: 52 % busy, 225 us per
-        // block (profiles/r03_h_vol32_fused_phases.txt).
+        // block (profiles/r03_i_vol32_fused_phases.txt).
         f4_t acc2[4];                            // conv2: accumulators of output row hprev, finished at the head of the next step
         bool pend = false;
         int hprev = 0;
