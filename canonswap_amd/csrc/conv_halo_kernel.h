@@ -309,6 +309,18 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #else
         constexpr int PFS = NS < 3 ? NS : (WCH * WPX <= 4 ? (NS < 8 ? NS : 8) : 3);
 #endif
+        // The ring is carried over the chunk boundary in the kernels that run one wave per SIMD (256-position tiles), where a chunk is a
+        // whole number of ring turns (3x3x3 x 32 channels: 27 steps): the last PFS steps of a chunk fetch the first PFS steps of the next
+        // one into the slots these expect, so the first MFMA behind the chunk barrier does not wait for an L2 round trip (wload_at clamps
+        // the chunk index: behind the last chunk the fetches repeat its first steps and are dropped).  The ragged chunk has another step
+        // count, but it is the last one.  Hourglass tail and first encoder block -4 %, +0.25 % on the step; with two or three waves per
+        // SIMD the others fill that gap already and the longer live ranges cost the 128x256 kernels 12-24 bytes of scratch: -0.2 %
+        // (profiles/r03_n_ab_wcarry.txt; -DCS_NO_WCARRY is the A/B switch).  The mask conv's 49 steps are not a multiple of 3.
+#ifdef CS_NO_WCARRY
+        constexpr bool WCARRY = false;
+#else
+        constexpr bool WCARRY = (NS % PFS == 0) && NS >= 2 * PFS && WPX == 8 && WVP == 2;
+#endif
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
         u4_t wr[PFS][WCH];
         // In this fully unrolled body hipcc counts vmcnt / lgkmcnt exactly (the only conservative drain sits at the chunk
@@ -327,8 +339,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         // head of a chunk: prime the weight ring, then wait for / re-issue the halo staging; returns the chunk's LDS buffer
         auto chunk_head = [&](int cc) -> const unsigned char* {
             // prime the ring with this chunk's first steps before waiting on the halo: both latencies overlap
+            if (!WCARRY || cc == cc_lo) {
 #pragma unroll
-            for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
+                for (int st = 0; st < PFS; ++st) wload_at(wr[st], cc, st);
+            }
             if (cc > cc_lo && !(p.hilo && cc == 1)) {      // hilo: weight chunk 1 reuses the staged hi halo
                 if (DB) {
                     __syncthreads();                       // chunk cc has landed in buffer (cc-cc_lo)&1; everyone left the other one
@@ -390,7 +404,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 const int toff = toff_of(st);
 #pragma unroll
                 for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + ab_of(pi, st) + toff);
-                if (ILV && st >= 1 && st - 1 + PFS < NSC) wload_at(wr[(st - 1) % PFS], cc, st - 1 + PFS);
+                if (ILV && st >= 1) {
+                    if (st - 1 + PFS < NSC) wload_at(wr[(st - 1) % PFS], cc, st - 1 + PFS);
+                    else if (WCARRY && !RAG) wload_at(wr[(st - 1) % PFS], cc + 1, st - 1 + PFS - NSC);
+                }
                 if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ci = 0; ci < WCH; ++ci)
@@ -422,8 +439,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                     for (int i = 0; i < HA; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (!ILV && st + PFS < NSC) wload_at(wr[st % PFS], cc, st + PFS);
+                if (!ILV) {
+                    if (st + PFS < NSC) wload_at(wr[st % PFS], cc, st + PFS);
+                    else if (WCARRY && !RAG) wload_at(wr[st % PFS], cc + 1, st + PFS - NSC);
+                }
             }
+            if (ILV && WCARRY && !RAG) wload_at(wr[(NSC - 1) % PFS], cc + 1, PFS - 1);
         };
         // the ragged chunk is peeled off the loop (inside it, the two bodies together cost the 160-wide kernels 500-650 bytes of scratch)
         const bool rag = RAGK && p.ragged && cc_hi == nck;

@@ -1,0 +1,9 @@
+#!/bin/bash
+# GPU box: alternating bench runs of the shipped library and ab/$1.so (python tools/build_variant.py NAME flags), no tests
+mkdir -p gpurun_out/ab_lib
+for i in 1 2 3; do for v in ab/$1.so ""; do
+  CANONSWAP_LIB=$v python bench.py --steps 10 --warmup 3 --no-fixed-job --no-cpu-baseline > gpurun_out/ab_lib/b.json 2>/dev/null
+  python - <<PY
+import json; d=json.load(open("gpurun_out/ab_lib/b.json")); print("lib=$v", d["value"], d["roofline"]["frac"], d["ms_per_step"])
+PY
+done; done
