@@ -113,6 +113,20 @@ def run_case(lib, name, kw, nsteps, mfma_per_step, slots, nrep=3):
                    T[:, 5] - T[:, 4]], axis=1)
     ncu = len(np.unique((t[:, 11] << 16) | ((t[:, 10] >> 8) & 0xFF)))
     kernel_ns = ms * 1e6
+    # one workgroup per CU: time between the end of a workgroup and the start of the next one on the same CU (s_memrealtime, 10 ns ticks)
+    gap_ns = -1.0
+    if slots == 1:
+        cu = (t[:, 11] << 16) | ((t[:, 10] >> 8) & 0xFFFF)
+        gaps = []
+        for c in np.unique(cu):
+            m = t[cu == c]
+            st = np.sort(np.unique(m[:, 8])); en = np.sort(np.unique(m[:, 9]))
+            # workgroup = 4 waves: take per workgroup the earliest start / latest end by clustering on start order
+            o = np.argsort(m[:, 8]); m = m[o]
+            wg_s = m[0::4, 8]; wg_e = np.maximum.reduceat(m[:, 9], np.arange(0, len(m), 4))
+            if len(wg_s) > 1:
+                gaps.extend(((wg_s[1:] - wg_e[:-1]) * 10.0).tolist())
+        gap_ns = float(np.median(gaps)) if gaps else -1.0
     slot_occ = life_ns.sum() / (ncu * slots * 4 * kernel_ns)          # share of the kernel a wave slot is occupied
     ideal_loop = nsteps * mfma_per_step * 16.0                        # cycles of back-to-back MFMA issue for one wave alone
     rec = {
@@ -123,6 +137,7 @@ def run_case(lib, name, kw, nsteps, mfma_per_step, slots, nrep=3):
         "phase_share": [round(float(v), 3) for v in ph.mean(axis=0) / life.mean()],
         "life_us_mean": round(float(life_ns.mean()) / 1e3, 2),
         "loop_over_ideal": round(float(ph[:, 2].mean()) / ideal_loop, 2),
+        "wg_gap_ns_p50": round(gap_ns, 0),
     }
     return rec
 
@@ -146,9 +161,9 @@ def main():
             continue
         rec = run_case(lib, name, kw, nsteps, mps, slots)
         recs.append(rec)
-        print("%-8s %7.3f ms  %.2f GHz  slot occ %.2f (%d WG/CU)  life %7.2f us  cycles %s  share %s  loop/ideal %.2f" % (
+        print("%-8s %7.3f ms  %.2f GHz  slot occ %.2f (%d WG/CU)  life %7.2f us  cycles %s  share %s  loop/ideal %.2f  wg gap %.0f ns" % (
             name, rec["ms"], rec["shader_ghz"], rec["slot_occupancy"], slots, rec["life_us_mean"],
-            [int(v) for v in rec["phase_cycles_mean"]], rec["phase_share"], rec["loop_over_ideal"]), flush=True)
+            [int(v) for v in rec["phase_cycles_mean"]], rec["phase_share"], rec["loop_over_ideal"], rec["wg_gap_ns_p50"]), flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(recs, open(a.out, "w"), indent=1)
 
