@@ -191,14 +191,32 @@ _Pragma("unroll") \
         } \
     }
 
-#define CONV_EPILOGUE() \
+#ifndef EP_FG
+#define EP_FG 8           /* position blocks fetched per round in the fast paths of the 128x256 kernels (the general path: 2 / 1) */
+#endif
+#ifndef EP_FG_F32
+#define EP_FG_F32 4         /* ... with an fp32 residual (16 registers per block) */
+#endif
+#ifndef EP_FG_STAT
+#define EP_FG_STAT 4
+#endif
+#define CONV_EPILOGUE_IMPL(EPCODE) \
+    constexpr int EPF = (EPCODE); \
+    constexpr bool EPFAST = EPF >= 0; \
+    constexpr bool EPALL = EPFAST && ((EPF >> 6) & 1) == 0;      /* every channel of the wave exists */ \
+    const bool ep_has_res = EPFAST ? ((EPF & 3) != 0) : (p.res.p != nullptr); \
+    const bool ep_res32 = EPFAST ? ((EPF & 3) == 2) : (p.res_f32 != 0); \
+    const bool ep_has_o0 = EPFAST ? (((EPF >> 2) & 1) != 0) : (p.out0.p != nullptr); \
+    const bool ep_o032 = EPFAST ? (((EPF >> 3) & 1) != 0) : (p.out0_f32 != 0); \
+    const bool ep_has_o1 = EPFAST ? (((EPF >> 4) & 1) != 0) : (p.out1.p != nullptr); \
+    const bool ep_has_ps = EPFAST ? (((EPF >> 5) & 1) != 0) : (p.pixscale != nullptr); \
     constexpr int CSTEP = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
     /* per-channel constants of this lane's 4 channels, loaded once (16-byte loads), not once per position block */ \
     float4 ep_bias[WCH], ep_bias2[WCH], ep_s2[WCH], ep_t2[WCH], ep_mean[WCH], ep_rstd[WCH]; \
 _Pragma("unroll") \
     for (int ci = 0; ci < WCH; ci += CSTEP) { \
         const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
-        const bool cok = cb < p.Cout; \
+        const bool cok = EPALL || cb < p.Cout; \
         ep_bias[ci] = (cok && p.bias) ? *(const float4*)(p.bias + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
         ep_bias2[ci] = (cok && MODE == MODE_SPADE) ? *(const float4*)(p.bias2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
         ep_s2[ci] = (cok && p.s2) ? *(const float4*)(p.s2 + cb) : make_float4(1.f, 1.f, 1.f, 1.f); \
@@ -231,13 +249,13 @@ _Pragma("unroll") \
     constexpr bool EP_PF = (WCH != 5); \
     /* position blocks fetched per round: the whole tile where the register budget allows (no scratch, same occupancy step - \
        checked with tools/kernel_resources.py), else groups of 4 (128x128 tiles held to 168 registers), 2 (128x256 non-blend) or 1 (128x256 with 32 statistics accumulators) */ \
-    constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? (EP_STAT ? 1 : 2) : 4))); \
+    constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? (EPFAST ? (EP_STAT ? EP_FG_STAT : ((EPF & 3) == 2 ? EP_FG_F32 : EP_FG)) : (EP_STAT ? 1 : 2)) : 4))); \
     constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
-    const bool ep_fetch = EP_PF && p.res.p != nullptr; \
+    const bool ep_fetch = EP_PF && ep_has_res; \
     /* channel pairs (EP_PAIR): fp16 tensors whose pointer and strides keep 8 channels 16-byte aligned get one access per pair */ \
-    const bool ep_m0 = EP_PAIR != 0 && !p.out0_f32 && ep_al8(p.out0); \
-    const bool ep_m1 = EP_PAIR != 0 && ep_al8(p.out1); \
-    const bool ep_mr = EP_PAIR != 0 && EP_PF && !p.res_f32 && ep_al8(p.res); \
+    const bool ep_m0 = EP_PAIR != 0 && !ep_o032 && (EPFAST || ep_al8(p.out0)); \
+    const bool ep_m1 = EP_PAIR != 0 && (EPFAST || ep_al8(p.out1)); \
+    const bool ep_mr = EP_PAIR != 0 && EP_PF && !ep_res32 && (EPFAST || ep_al8(p.res)); \
     const int ep_rshift = (MODE == MODE_SPADE) ? p.res_shift : 0; \
     /* Addressing.  A position of the tile is m = blk * 16 + l15 with blk = ep_wpx * EP_WPX + pi uniform over the wave; the tile's \
        (w, h, d, n) are disjoint bit fields of m, so every coordinate - also after the >> of an up-sampled operand - is the sum of a \
@@ -264,23 +282,23 @@ _Pragma("unroll") \
 _Pragma("unroll") \
     for (int pg = 0; pg < EP_WPX; pg += EP_G) { \
     ep_u4_t ep_raw[EP_G][EP_NCI]; float ep_ps[EP_G]; \
-    if (EP_PF && !EP_EARLY && (ep_fetch || p.pixscale)) { \
+    if (EP_PF && !EP_EARLY && (ep_fetch || ep_has_ps)) { \
 _Pragma("unroll") \
         for (int g = 0; g < EP_G; ++g) { \
             int bw, bh, bd, bn; \
             { int t = (ep_wpx * EP_WPX + pg + g) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
-            if (ep_nb + ep_ln + bn >= p.N) continue; \
-            if (p.pixscale) ep_ps[g] = p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
+            if (!EPFAST && ep_nb + ep_ln + bn >= p.N) continue; \
+            if (ep_has_ps) ep_ps[g] = p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
             if (ep_fetch) { \
                 const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + \
                                                             (bw >> ep_rs) * (int)p.res.sW); \
 _Pragma("unroll") \
                 for (int ci = 0; ci < WCH; ci += CSTEP) { \
                     const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
-                    if (cb >= p.Cout) continue; \
-                    if (p.res_f32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + (xb + (unsigned)cb)); \
+                    if (!EPALL && cb >= p.Cout) continue; \
+                    if (ep_res32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + (xb + (unsigned)cb)); \
                     else if (ep_mr && ep_second(EP_PAIR, ci)) { /* came with the pair's first half */ } \
-                    else if (ep_mr && cb + 4 < p.Cout) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
+                    else if (ep_mr && (EPALL || cb + 4 < p.Cout)) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
                     else { \
                         const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
                         ep_raw[g][(EP_PF ? ci / CSTEP : 0)][0] = q2[0]; ep_raw[g][(EP_PF ? ci / CSTEP : 0)][1] = q2[1]; \
@@ -297,9 +315,9 @@ _Pragma("unroll") \
         if (pi > 0 && pi % EP_SG == 0) { EP_STAT_FLUSH(pi / EP_SG - 1) } \
         int bw, bh, bd, bn; \
         { int t = (ep_wpx * EP_WPX + pi) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
-        if (ep_nb + ep_ln + bn >= p.N) continue; \
+        if (!EPFAST && ep_nb + ep_ln + bn >= p.N) continue; \
         float ps = 1.f; \
-        if (p.pixscale) ps = EP_PF ? ep_ps[g] : p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
+        if (ep_has_ps) ps = EP_PF ? ep_ps[g] : p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
         const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + (bw >> ep_rs) * (int)p.res.sW); \
         const unsigned ob0 = ep_lane_o0 + (unsigned)(bn * (int)p.out0.sN + bd * (int)p.out0.sD + bh * (int)p.out0.sH + bw * (int)p.out0.sW); \
         const unsigned ob1 = ep_lane_o1 + (unsigned)(bn * (int)p.out1.sN + bd * (int)p.out1.sD + bh * (int)p.out1.sH + bw * (int)p.out1.sW); \
@@ -307,9 +325,9 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
             const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
-            if (cb >= p.Cout) continue; \
+            if (!EPALL && cb >= p.Cout) continue; \
             float rr[4] = {0.f, 0.f, 0.f, 0.f};     /* residual (STD / TBLEND) or the modulated tensor x (SPADE) */ \
-            if (p.res.p) { \
+            if (ep_has_res) { \
                 if (EP_EARLY) { \
                     const h4_t hx = __builtin_bit_cast(h4_t, ep_xpre[EP_EARLY ? pi : 0][EP_EARLY ? ci / 2 : 0]); \
 _Pragma("unroll") \
@@ -318,7 +336,7 @@ _Pragma("unroll") \
                     const bool ep_hi = ep_mr && ep_second(EP_PAIR, ci);      /* upper half of the pair's 16-byte fetch */ \
                     const ep_u4_t q4 = ep_raw[g][(EP_PF ? ci / CSTEP : 0)]; \
                     const ep_u4_t qp = ep_raw[g][(EP_PF && ep_second(EP_PAIR, ci) ? ci / CSTEP - 1 : 0)]; \
-                    if (p.res_f32) { \
+                    if (ep_res32) { \
                         const f4_t qf = __builtin_bit_cast(f4_t, q4);     /* whole-vector cast: bit_cast of q4[r] reads element 0 */ \
 _Pragma("unroll") \
                         for (int r = 0; r < 4; ++r) rr[r] = qf[r]; \
@@ -329,7 +347,7 @@ _Pragma("unroll") \
                         for (int r = 0; r < 4; ++r) rr[r] = (float)hx[r]; \
                     } \
                 } else { \
-                    load4(p.res, p.res_f32, (long)(xb + (unsigned)cb), rr); \
+                    load4(p.res, ep_res32, (long)(xb + (unsigned)cb), rr); \
                 } \
             } \
             float v[4]; \
@@ -371,22 +389,22 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \
-            const bool ep_hold = EP_PAIR != 0 && !ep_second(EP_PAIR, ci) && cb + 4 < p.Cout;      /* first half of a complete pair */ \
-            if (p.out0.p EP_STORE_COND) { \
+            const bool ep_hold = EP_PAIR != 0 && !ep_second(EP_PAIR, ci) && (EPALL || cb + 4 < p.Cout);      /* first half of a complete pair */ \
+            if (ep_has_o0 EP_STORE_COND) { \
                 if (ep_m0 && ep_hold) { \
 _Pragma("unroll") \
                     for (int r = 0; r < 4; ++r) ep_vh[r] = v[r]; \
                 } else if (ep_m0 && ep_second(EP_PAIR, ci)) store8(p.out0, 0, (long)(ob0 + (unsigned)(cb - 4)), ep_vh, v); \
-                else store4(p.out0, p.out0_f32, (long)(ob0 + (unsigned)cb), v); \
+                else store4(p.out0, ep_o032, (long)(ob0 + (unsigned)cb), v); \
             } \
             if (EP_STAT) { /* statistics of the values as stored (fp16-rounded when out0 is fp16) */ \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
-                    const float vs = p.out0_f32 ? v[r] : (float)(half_t)v[r]; \
+                    const float vs = ep_o032 ? v[r] : (float)(half_t)v[r]; \
                     ep_sum[EP_STAT ? ci : 0][r] += vs; ep_sq[EP_STAT ? ci : 0][r] = fmaf(vs, vs, ep_sq[EP_STAT ? ci : 0][r]); \
                 } \
             } \
-            if (p.out1.p) { \
+            if (ep_has_o1) { \
                 float u[4]; \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
@@ -406,4 +424,47 @@ _Pragma("unroll") \
     } \
     EP_STAT_FLUSH((EP_WPX - 1) / EP_SG)
 
-
+// Fast paths.  The general epilogue decides per element, at run time, whether a residual / second output / per-position scale exists, in
+// which precision, whether a channel pair can go out as one 16-byte access and whether the lane's sample and channels exist.  hipcc turns
+// that into ~300 branches with the fetches inside them and an `s_waitcnt vmcnt(0)` at every join (78-90 per wave in the 128x256 kernels of
+// modes STD / SPADE / STDSTAT; the T blend kernel, whose tensors happen to take one path, has 2): every fetch waits for its own round trip
+// and - vmcnt counts stores too - for the acknowledgement of every store before it.  The epilogue was 44 % of a SPADE workgroup's life
+// (profiles/r03_o_timeline_spade.txt).  EP_FAST kernels therefore test ONCE per wave whether the launch is one of the combinations the
+// engine's hot layers use (code: bits 1:0 residual none / fp16 / fp32, bit 2 out0, bit 3 out0 fp32, bit 4 out1, bit 5 per-position
+// scale) with every channel of the wave and every sample of the tile valid and the fp16 tensors 16-byte aligned, and run a copy of the
+// same epilogue with those facts as compile-time constants: no branches around fetches or stores, counted waits.  Same arithmetic, same
+// bits.  Expects EP_FAST (constexpr bool) in scope.
+#define EP_CODE(res, o0, o0f32, o1, ps) ((res) | ((o0) << 2) | ((o0f32) << 3) | ((o1) << 4) | ((ps) << 5))
+#define EP_RAGGED 64          /* not every channel of the wave exists (kernels without channel pairs only: the 160-wide tiles) */
+#define CONV_EPILOGUE() \
+    { \
+        int ep_code = -1; \
+        if constexpr (EP_FAST) { \
+            constexpr int CST = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
+            const int ep_r0 = n0 + wch * WCH * 16; \
+            const int ep_chi = (ep_r0 + WCH * 16) / CST;              /* one past the wave's last output channel */ \
+            const bool ep_call = ep_chi <= p.Cout && (p.Cout & 7) == 0; \
+            const bool ep_ok = (ep_call || (EP_PAIR == 0 && (p.Cout & 3) == 0)) && (tn + 1) * (BM >> lgS) <= p.N && \
+                               (!p.res.p || p.res_f32 || EP_PAIR == 0 || ep_al8(p.res)) && \
+                               (!p.out0.p || p.out0_f32 || EP_PAIR == 0 || ep_al8(p.out0)) && (!p.out1.p || EP_PAIR == 0 || ep_al8(p.out1)); \
+            if (ep_ok) ep_code = EP_CODE(p.res.p ? (p.res_f32 ? 2 : 1) : 0, p.out0.p ? 1 : 0, p.out0_f32 ? 1 : 0, p.out1.p ? 1 : 0, p.pixscale ? 1 : 0) | \
+                                 (ep_call ? 0 : EP_RAGGED); \
+        } \
+        bool ep_done = false; \
+        if constexpr (EP_FAST && MODE == MODE_SPADE) { \
+            if (ep_code == EP_CODE(1, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 1, 0, 0, 0)); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && (MODE == MODE_STD || MODE == MODE_STDSTAT)) { \
+            if (ep_code == EP_CODE(0, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 0, 0, 0)); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && (MODE == MODE_STD || MODE == MODE_STDSTAT) && WCH != 5) { \
+            if (ep_code == EP_CODE(1, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 1, 0, 0, 0)); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && MODE == MODE_STD && WCH == 4) { \
+            if (ep_code == EP_CODE(2, 1, 1, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(2, 1, 1, 1, 0)); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && MODE == MODE_STD && WCH == 5) { \
+            if (ep_code == (EP_CODE(0, 1, 0, 0, 0) | EP_RAGGED)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 0, 0, 0) | EP_RAGGED); ep_done = true; } \
+        } \
+        if (!ep_done) { CONV_EPILOGUE_IMPL(-1); } \
+    }

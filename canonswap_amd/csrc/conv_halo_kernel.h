@@ -147,6 +147,14 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     TL_STAMP(0);
 #endif
 
+#ifdef CS_DEPHASE        // experiment: workgroups of the first dispatch round in an odd wave slot start CS_DEPHASE x 1024 cycles late
+    if (MODE == MODE_SPADE && WCH == 4) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if ((hwid & 1u) && (int)(blockIdx.x + blockIdx.y * gridDim.x) < 512)
+            for (int i = 0; i < CS_DEPHASE; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wpx = SK ? 0 : wave % WVP, wch = SK ? 0 : wave / WVP;
@@ -285,6 +293,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr bool EP_EARLY = false;
 #else
     constexpr bool EP_EARLY = (MODE == MODE_SPADE) && !SK && ST != 0 && WCH == 2 && WPX == 8;
+#endif
+    // branch-free copies of the epilogue for the tensor combinations of the engine's hot layers (conv_epilogue.h, CONV_EPILOGUE)
+#ifdef CS_NO_EPFAST
+    constexpr bool EP_FAST = false;
+#else
+    constexpr bool EP_FAST = !SK && ST != 0 && (WCH == 4 || WCH == 5 || (WCH == 2 && WPX == 8));
 #endif
     constexpr int EP_WPX0 = WPX;
     const int ep_wpx0 = wpx;

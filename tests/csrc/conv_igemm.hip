@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p)
     constexpr int EP_WPX = WPX;
     constexpr int EP_PAIR = 0;           // weights go through LDS here: plain row order
     constexpr bool EP_EARLY = false;
+    constexpr bool EP_FAST = false;
     const int l15p = l15;
     ep_u2_t ep_xpre[1][1];
     constexpr bool EP_HEAVY = true;      // the cross-check kernel carries every activation

@@ -62,6 +62,9 @@ def cases(B, r):
     out.append(("G.gb512", dict(x=xa, w=wgt(128, 1024, (1, 3, 3)), cout_pad=1024, cout=512, k=(1, 3, 3), mode=2, bias=rn(512, dtype=np.float32),
                                 bias2=rn(512, dtype=np.float32), res=rn(B, 1, 64, 64, 512), stats=st, act0="lrelu", slope0=0.2,
                                 out0=torch.empty(B, 1, 64, 64, 512, dtype=torch.float16, device=DEV), cfg=10), 36, 8 * 2, 3))
+    out.append(("G.gb512w", dict(x=xa, w=wgt(128, 1024, (1, 3, 3)), cout_pad=1024, cout=512, k=(1, 3, 3), mode=2, bias=rn(512, dtype=np.float32),
+                                 bias2=rn(512, dtype=np.float32), res=rn(B, 1, 64, 64, 512), stats=st, act0="lrelu", slope0=0.2,
+                                 out0=torch.empty(B, 1, 64, 64, 512, dtype=torch.float16, device=DEV), cfg=17), 36, 8 * 4, 2))
     # dense-motion hourglass: tail, mask, first encoder block
     Bd = min(B, 16)
     xd = torch.relu(rn(Bd, 16, 64, 64, 144))
@@ -111,6 +114,9 @@ def run_case(lib, name, kw, nsteps, mfma_per_step, slots, nrep=3):
     #         remaining blocks | store drain
     ph = np.stack([T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2], T[:, 6] - T[:, 3], T[:, 7] - T[:, 6], T[:, 4] - T[:, 7],
                    T[:, 5] - T[:, 4]], axis=1)
+    if os.environ.get("TL_SLOTS"):
+        print("   wave slots (HW_ID[3:0]) histogram:", np.bincount((t[:, 10] & 0xF).astype(np.int64), minlength=16).tolist(),
+              " simd (HW_ID[5:4]):", np.bincount(((t[:, 10] >> 4) & 3).astype(np.int64), minlength=4).tolist())
     ncu = len(np.unique((t[:, 11] << 16) | ((t[:, 10] >> 8) & 0xFF)))
     kernel_ns = ms * 1e6
     # one workgroup per CU: time between the end of a workgroup and the start of the next one on the same CU (s_memrealtime, 10 ns ticks)
