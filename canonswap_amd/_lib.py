@@ -139,9 +139,11 @@ def isa_check(obj_dir: str | None = None) -> dict:
                              txt, re.S | re.M):
             name, wch, body = m.group(1), int(m.group(2)), m.group(3).split("\n")
             want = f"s_waitcnt vmcnt({3 * wch})"
-            waits = [i for i, l in enumerate(body) if l.strip().startswith(want) and "lgkmcnt" not in l]
-            if len(waits) != 4:
+            kend = max(i for i, l in enumerate(body) if "v_mfma" in l)        # the epilogue's own (compiler-counted) waits are not the ring's
+            waits = [i for i, l in enumerate(body) if i < kend and l.strip().startswith(want) and "lgkmcnt" not in l]
+            if len(waits) < 4:
                 raise RuntimeError(f"isa_check: {name}: {len(waits)} x `{want}` in the K loop, expected 4 (one per ring slot)")
+            waits = waits[:4]     # (a later wait with the same count is the compiler's own, for the spill stores of the loop's drain)
             loads = [(i, re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off", l)) for i, l in enumerate(body)]
             loads = [(i, int(q.group(1))) for i, q in loads if q]
             prime = [r for i, r in loads if i < waits[0]][-4 * wch:]          # the ring as the prologue primed it: 4 slots x WCH fragments
@@ -188,6 +190,7 @@ class ConvDesc(C.Structure):
         ("hilo", C.c_int), ("stat_out", C.c_void_p),
         ("xf_kind", C.c_int), ("xf_y", C.c_void_p), ("xf_res", C.c_void_p), ("xf_out", C.c_void_p),
         ("xf_stats", C.c_void_p), ("xf_gamma", C.c_void_p), ("xf_beta", C.c_void_p), ("xf_slope", C.c_float),
+        ("ep_general", C.c_int),
     ]
 
 

@@ -109,6 +109,8 @@ struct ConvParams {
     // and stores 8 logit vectors per tile row: kw_out[((n * D + d) * H + h) * (W / 2) + tile][j][22], j <-> output column w0 - 3 + j
     // (dense_motion.py:88: logit(w) = sum_kw part[w + kw - 3][kw]).  45 % fewer bytes on both sides of the hand-over to the softmax.
     float* kw_out;
+    // tests / A/B (CANONSWAP_EP_GENERAL=1): run the general epilogue where the kernel also carries branch-free copies (conv_epilogue.h)
+    int ep_general;
     int xf_kind;
     TDesc xf_y, xf_res, xf_out;
     const float* xf_stats; const float* xf_gamma; const float* xf_beta;

@@ -63,17 +63,33 @@ __device__ __forceinline__ void load4(const TDesc& t, int is_f32, long off, floa
 
 // Ablation build (tools/build_variant.py, not the product): -DCS_EP_NOSTORE puts every epilogue store behind a runtime condition
 // that is never true (what the stores cost: profiles/r02_store_ablation.txt).
+// fp32 -> fp16 of values the epilogue computed: round-to-nearest-even of the fp32 RESULT.  Left to itself hipcc folds a preceding fma
+// into v_fma_mix{lo,hi}_f16 (one rounding, straight from the exact product-sum to fp16; an instruction-selection pattern, not governed by
+// the contraction pragma) for some elements and not for others, depending on the code around it - the branch-free copies of the epilogue
+// then differ from the general one in the last bit of values that sit on an fp16 rounding boundary (tests/test_gpu_epilogue_fast.py).
+// The conversion is therefore written as the instruction the compiler uses anyway, where it cannot be folded into.
+__device__ __forceinline__ unsigned ep_pk(float a, float b)          // (fp16(a), fp16(b)) in one register
+{
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ half_t ep_h(float v)
+{
+    const unsigned r = ep_pk(v, v);
+    return __builtin_bit_cast(half_t, (unsigned short)(r & 0xFFFFu));
+}
+
 __device__ __forceinline__ void store4(const TDesc& t, int is_f32, long off, const float v[4])
 {
     if (is_f32) {
         *(float4*)((float*)t.p + off) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-        h4_t x;
-        x[0] = (half_t)v[0]; x[1] = (half_t)v[1]; x[2] = (half_t)v[2]; x[3] = (half_t)v[3];
-        *(h4_t*)((half_t*)t.p + off) = x;
+        ep_u2_t x;
+        x[0] = ep_pk(v[0], v[1]); x[1] = ep_pk(v[2], v[3]);
+        *(ep_u2_t*)((half_t*)t.p + off) = x;
     }
 }
-
 
 __device__ __forceinline__ void store8(const TDesc& t, int is_f32, long off, const float a[4], const float b[4])
 {
@@ -81,10 +97,9 @@ __device__ __forceinline__ void store8(const TDesc& t, int is_f32, long off, con
         *(float4*)((float*)t.p + off) = make_float4(a[0], a[1], a[2], a[3]);
         *(float4*)((float*)t.p + off + 4) = make_float4(b[0], b[1], b[2], b[3]);
     } else {
-        h8_t x;
-        x[0] = (half_t)a[0]; x[1] = (half_t)a[1]; x[2] = (half_t)a[2]; x[3] = (half_t)a[3];
-        x[4] = (half_t)b[0]; x[5] = (half_t)b[1]; x[6] = (half_t)b[2]; x[7] = (half_t)b[3];
-        *(h8_t*)((half_t*)t.p + off) = x;
+        ep_u4_t x;
+        x[0] = ep_pk(a[0], a[1]); x[1] = ep_pk(a[2], a[3]); x[2] = ep_pk(b[0], b[1]); x[3] = ep_pk(b[2], b[3]);
+        *(ep_u4_t*)((half_t*)t.p + off) = x;
     }
 }
 
@@ -360,7 +375,7 @@ _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
                     const float gm = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
                     const float bt = ep_acc[ci + CSTEP - 1][pi][r] + ((const float*)&ep_bias2[ci])[r]; \
-                    v[r] = (rr[r] - ((const float*)&ep_mean[ci])[r]) * ((const float*)&ep_rstd[ci])[r] * (1.f + gm) + bt; \
+                    v[r] = fmaf((rr[r] - ((const float*)&ep_mean[ci])[r]) * ((const float*)&ep_rstd[ci])[r], 1.f + gm, bt); \
                 } \
             } else { \
 _Pragma("unroll") \
@@ -400,7 +415,7 @@ _Pragma("unroll") \
             if (EP_STAT) { /* statistics of the values as stored (fp16-rounded when out0 is fp16) */ \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
-                    const float vs = ep_o032 ? v[r] : (float)(half_t)v[r]; \
+                    const float vs = ep_o032 ? v[r] : (float)ep_h(v[r]); \
                     ep_sum[EP_STAT ? ci : 0][r] += vs; ep_sq[EP_STAT ? ci : 0][r] = fmaf(vs, vs, ep_sq[EP_STAT ? ci : 0][r]); \
                 } \
             } \
@@ -408,7 +423,7 @@ _Pragma("unroll") \
                 float u[4]; \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
-                    const float a = v[r] * ((const float*)&ep_s2[ci])[r] + ((const float*)&ep_t2[ci])[r]; \
+                    const float a = fmaf(v[r], ((const float*)&ep_s2[ci])[r], ((const float*)&ep_t2[ci])[r]);   /* explicit: every copy of the epilogue fuses alike */ \
                     u[r] = lin_act(a, ep_sl1); \
                 } \
                 if (true EP_STORE_COND) { \
@@ -444,7 +459,7 @@ _Pragma("unroll") \
             const int ep_r0 = n0 + wch * WCH * 16; \
             const int ep_chi = (ep_r0 + WCH * 16) / CST;              /* one past the wave's last output channel */ \
             const bool ep_call = ep_chi <= p.Cout && (p.Cout & 7) == 0; \
-            const bool ep_ok = (ep_call || (EP_PAIR == 0 && (p.Cout & 3) == 0)) && (tn + 1) * (BM >> lgS) <= p.N && \
+            const bool ep_ok = !p.ep_general && (ep_call || (EP_PAIR == 0 && (p.Cout & 3) == 0)) && (tn + 1) * (BM >> lgS) <= p.N && \
                                (!p.res.p || p.res_f32 || EP_PAIR == 0 || ep_al8(p.res)) && \
                                (!p.out0.p || p.out0_f32 || EP_PAIR == 0 || ep_al8(p.out0)) && (!p.out1.p || EP_PAIR == 0 || ep_al8(p.out1)); \
             if (ep_ok) ep_code = EP_CODE(p.res.p ? (p.res_f32 ? 2 : 1) : 0, p.out0.p ? 1 : 0, p.out0_f32 ? 1 : 0, p.out1.p ? 1 : 0, p.pixscale ? 1 : 0) | \

@@ -21,7 +21,16 @@ static int launch_halo_cfg(const ConvParams& p, hipStream_t st)
             p.nchunks % (CK / 32) == 0)
             return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, STV>(p, st);
     }
-    return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, 0>(p, st);
+    // The 128x256 statistics tile has no dynamic-shape variant: with the 32 statistics accumulators on top of 128 accumulator registers
+    // hipcc spills the hand-counted weight ring of the dynamic K loop (the loads it does not track: _lib.isa_check), and no layer needs it
+    // (every conv that emits statistics is a 3x3 or 3x3x3 on one of the static tiles).
+    if constexpr (WCH == 4 && MODE == MODE_STDSTAT) {
+        cs_set_error("conv_halo: the 128x256 statistics tile exists for the static shapes only (%dx%dx%d taps, tile 2^%d x 2^%d x 2^%d)",
+                     p.KD, p.KH, p.KW, p.lgTW, p.lgTH, p.lgTD);
+        return -1;
+    } else {
+        return launch_halo_st<CK, WPX, WCH, WVP, WVC, MODE, SK, 0>(p, st);
+    }
 }
 
 #define HALO_CASE(CFG, WPX, WCH, WVP, WVC, MODE, SK, ST2D, ST3D)                                         \

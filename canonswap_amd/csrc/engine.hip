@@ -346,6 +346,10 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         const bool spade_ck32 = spade32 && c.mode == MODE_SPADE && !(spade256() && c.p.Cout_pad % 256 == 0);
         const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !spade_ck32) ? 64 : 32;
         c.p.xcd_map = xcd_map_default();
+        {
+            static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
+            c.p.ep_general = epg;
+        }
         {   // cross-workgroup split-K when the launch cannot fill the chip (single-frame latency: the deep hourglass levels run 8-64
             // workgroups that each stream megabytes of weights): plain bias + activation + one output only
             // Split sums are added in another order than one workgroup's sequential accumulation, so results differ in the last
@@ -1537,6 +1541,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
         const int ck = d->ck ? d->ck : ((!is3d && p.Cin % 64 == 0) ? 64 : 32);
         p.xcd_map = d->xcd_map > 0 ? d->xcd_map - 1 : xcd_map_default();
         p.ragged = d->ragged;
+        p.ep_general = d->ep_general;
         return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);
     }
     cs_set_error("cs_op_conv: cfg %d is not a conv_halo configuration (the conv_igemm cross-check kernel lives in the test-only library)", d->cfg);

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
             } else {
                 h8_t x;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) x[r] = (half_t)ov[c][r];
+                for (int r = 0; r < 8; ++r) x[r] = ep_h(ov[c][r]);
                 *(h8_t*)((half_t*)p.out0 + o) = x;
             }
         };
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                     if constexpr (EPI == V_EPI_STAT) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
                     if constexpr (EPI == V_EPI_RES) {
                         const float a = v * s2_v[r] + t2_v[r];
-                        ou[c][r] = (half_t)lin_act(a, p.sl1);
+                        ou[c][r] = ep_h(lin_act(a, p.sl1));
                     }
                 }
             }

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
                     v += rr[c][r];
                     ov[c][r] = v;
                     const float a2 = v * s2_v[r] + t2_v[r];
-                    uu[r] = (half_t)lin_act(a2, p.sl1);
+                    uu[r] = ep_h(lin_act(a2, p.sl1));
                 }
                 ou[c] = __builtin_bit_cast(ep_u2_t, uu);
             }
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(512, 2) vol32_fused_kernel(const FusedParams p
                         const bool in = row_in && (unsigned)(w0 - 1 + 5 * chf + c) < (unsigned)p.W;
                         h4_t hv;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) hv[r] = in ? (half_t)lin_act(acc[c][r] + bias_v[r], 0.f) : (half_t)0.f;
+                        for (int r = 0; r < 4; ++r) hv[r] = in ? ep_h(lin_act(acc[c][r] + bias_v[r], 0.f)) : (half_t)0.f;
                         *(h4_t*)(hrow + c * F_CS) = hv;
                     }
                     FTL(4);

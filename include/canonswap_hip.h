@@ -149,6 +149,7 @@ typedef struct cs_conv_desc {
     const float* xf_y; const float* xf_res; float* xf_out;
     const float* xf_stats; const float* xf_gamma; const float* xf_beta;
     float xf_slope;
+    int ep_general;           /* tests / A/B: 1 forces the general epilogue where a kernel also carries branch-free copies of it (same bits) */
 } cs_conv_desc;
 int cs_op_conv(const cs_conv_desc* d, void* stream);
 /* in place: re-pack the last 32-channel chunk of a packed conv weight [chunks * taps][Cout_pad][32] (Cin % 32 == 16) so that two
