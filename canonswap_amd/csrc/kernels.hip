@@ -192,6 +192,9 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
         const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
         const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
+        // the eight corners are fetched unconditionally (clamped address, weight 0 outside the volume: fmaf(0, c, a) == a, the same bits as
+        // skipping the corner) so that the loads go out back to back; behind a bounds test each one waited for its own round trip
+        h4_t cv[8]; float wv[8];
 #pragma unroll
         for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
@@ -199,13 +202,16 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
-                    if ((unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D) {
-                        const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
-                        const h4_t c = *(const h4_t*)(base + (((long)zc * H + yc) * W + xc) * 4);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = fmaf(wgt, (float)c[j], a[j]);
-                    }
+                    const bool in = (unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D;
+                    const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                    const int xq = min(max(xc, 0), W - 1), yq = min(max(yc, 0), H - 1), zq = min(max(zc, 0), D - 1);
+                    cv[dz * 4 + dy * 2 + dx] = *(const h4_t*)(base + (((long)zq * H + yq) * W + xq) * 4);
+                    wv[dz * 4 + dy * 2 + dx] = in ? wgt : 0.f;
                 }
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = fmaf(wv[c8], (float)cv[c8][j], a[j]);
         o[0] = (half_t)heat;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[1 + j] = (half_t)a[j];
@@ -375,6 +381,8 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
         const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
         const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
+        // all eight corners fetched back to back (clamped address, weight 0 outside: the same bits as skipping them; see dm_sparse_kernel)
+        float4 cv[8]; float wv[8];
 #pragma unroll
         for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
@@ -382,12 +390,17 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
-                    if ((unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D) {
-                        const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
-                        const float4 c = *(const float4*)(base + (((long)yc * W + xc) * D + zc) * 32);
-                        a[0] = fmaf(wgt, c.x, a[0]); a[1] = fmaf(wgt, c.y, a[1]); a[2] = fmaf(wgt, c.z, a[2]); a[3] = fmaf(wgt, c.w, a[3]);
-                    }
+                    const bool inb = (unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D;
+                    const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                    const int xq = min(max(xc, 0), W - 1), yq = min(max(yc, 0), H - 1), zq = min(max(zc, 0), D - 1);
+                    cv[dz * 4 + dy * 2 + dx] = *(const float4*)(base + (((long)yq * W + xq) * D + zq) * 32);
+                    wv[dz * 4 + dy * 2 + dx] = inb ? wgt : 0.f;
                 }
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            a[0] = fmaf(wv[c8], cv[c8].x, a[0]); a[1] = fmaf(wv[c8], cv[c8].y, a[1]);
+            a[2] = fmaf(wv[c8], cv[c8].z, a[2]); a[3] = fmaf(wv[c8], cv[c8].w, a[3]);
+        }
         const long vo = ((((long)n * H + y) * W + wb * 16 + wl) * D + d) * 32 + cg * 4;
         if (out32) *(float4*)(out32 + vo) = make_float4(a[0], a[1], a[2], a[3]);
         if (out16) {
@@ -460,6 +473,7 @@ __global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restric
     const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     const float* base = in + (long)n * H * W * D * 32 + cg * 4;
+    float4 cv[8]; float wv[8];           // all eight corners fetched back to back (see dm_sparse_kernel)
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
@@ -467,12 +481,17 @@ __global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restric
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
-                if ((unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D) {
-                    const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
-                    const float4 c = *(const float4*)(base + (((long)yc * W + xc) * D + zc) * 32);
-                    a[0] = fmaf(wgt, c.x, a[0]); a[1] = fmaf(wgt, c.y, a[1]); a[2] = fmaf(wgt, c.z, a[2]); a[3] = fmaf(wgt, c.w, a[3]);
-                }
+                const bool inb = (unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D;
+                const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                const int xq = min(max(xc, 0), W - 1), yq = min(max(yc, 0), H - 1), zq = min(max(zc, 0), D - 1);
+                cv[dz * 4 + dy * 2 + dx] = *(const float4*)(base + (((long)yq * W + xq) * D + zq) * 32);
+                wv[dz * 4 + dy * 2 + dx] = inb ? wgt : 0.f;
             }
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        a[0] = fmaf(wv[c8], cv[c8].x, a[0]); a[1] = fmaf(wv[c8], cv[c8].y, a[1]);
+        a[2] = fmaf(wv[c8], cv[c8].z, a[2]); a[3] = fmaf(wv[c8], cv[c8].w, a[3]);
+    }
     if (out32) *(float4*)(out32 + v * 32 + cg * 4) = make_float4(a[0], a[1], a[2], a[3]);
     if (out16) {
         h4_t o; o[0] = (half_t)a[0]; o[1] = (half_t)a[1]; o[2] = (half_t)a[2]; o[3] = (half_t)a[3];
