@@ -73,6 +73,14 @@ GROUP_FN(1)     // mlp_shared phase convs (1x2x2 family, ahead of the generic 12
         return launch_halo_cfg<64, 8, 2, 1, 4, MODE_STD, false, 15>(p, st);
     }
     if (cfg == CFG_H_256x64 && mode == MODE_STD && ck == 32) return launch_halo_cfg<32, 8, 2, 2, 2, MODE_STD, false, 7>(p, st);
+    if (cfg == CFG_H_256x64 && ck == 64) {        // 2-D 3x3 on 16x16 tiles, static shape only
+        if (p.KD != 1 || p.KH != 3 || p.KW != 3 || p.lgTW != 4 || p.lgTH != 4 || p.lgTD != 0) {
+            cs_set_error("conv_halo: the 2-D 256x64 tile runs 3x3 convs on 16x16 tiles only");
+            return -1;
+        }
+        if (mode == MODE_STD) return launch_halo_st<64, 8, 2, 2, 2, MODE_STD, false, 16>(p, st);
+        if (mode == MODE_STDSTAT) return launch_halo_st<64, 8, 2, 2, 2, MODE_STDSTAT, false, 16>(p, st);
+    }
     if (cfg == CFG_H_256x160 && mode == MODE_STD && ck == 32) {
         if (p.KD == 7) return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 8>(p, st);
         return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 7>(p, st);

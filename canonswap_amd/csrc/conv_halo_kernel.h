@@ -55,6 +55,7 @@ extern long g_cs_tl_cap;
 //   ST 0: everything dynamic     ST 1: 1x3x3, tile 16x8        ST 2: 3x3x3, tile 8x8x2       ST 3: 3x3x3, tile 4x4x16
 //   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
 //   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
+//   ST 16: 1x3x3, tile 16x16 (256 positions x 64 channels: the 64-channel 3x3 convs of G's last up block and F's first down block)
 //   ST 12 / 13: 3x2x2, tiles 4x4x16 and 8x8x2 (the hourglass up-blocks per output phase on the source grid)
 //   ST 10 / 11 / 14 / 15: 1x2x2, 1x2x1, 1x1x2, 1x1x1, tile 16x8 (the per-phase convs of mlp_shared on the up-sampled seg, run_G)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
@@ -66,6 +67,7 @@ template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3,
 template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
 template <> struct StaticShape<7> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 2; };   // 256 positions: 8x8x4
 template <> struct StaticShape<8> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 4; };   // 256 positions: 2x8x16
+template <> struct StaticShape<16> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 4, LD = 0; };   // 256 positions: 16x16 (2-D)
 template <> struct StaticShape<12> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 4; };
 template <> struct StaticShape<13> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 3, LH = 3, LD = 1; };
 template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 2, LW = 4, LH = 3, LD = 0; };
@@ -89,6 +91,7 @@ template <int CK, int WPX, int WCH, int WVP, int ST, int MODE> constexpr int hal
 #else
     if (CK == 64 && WCH == 4 && WPX == 8 && ST == 1) return 2;                       // 128x256 tiles (T, wide G / R convs): 2 workgroups per CU
     if (CK == 32 && WCH == 5 && WPX == 8 && (ST == 7 || ST == 8)) return 2;           // 256x160 tiles: 1 workgroup per CU
+    if (CK == 64 && WCH == 2 && WPX == 8 && WVP == 2 && ST == 16) return 2;           // 256x64 2-D tiles: 2 workgroups per CU (2 x 52 KB)
     // SPADE gamma/beta convs (128x128, three workgroups per CU): the 64-channel image would not fit three times with two pad slots
     // (173 KB) and measured slower at two workgroups; with 32-channel chunks it does (104 KB) - the engine launches them that way
     if (CK == 32 && WCH == 2 && WPX == 8 && ST == 1 && MODE == MODE_SPADE) return 2;
@@ -101,7 +104,7 @@ template <int CK, int WPX, int WCH, int WVP, int ST, int MODE> constexpr int hal
 // pieces per thread whose source offsets are kept in registers = ceil(halo voxels * slots per voxel / 256)
 template <int ST, int PAD> constexpr int halo_hi()
 {
-    if (PAD == 2) return ST == 3 ? 16 : ((ST == 7 || ST == 8) ? 15 : 8);
+    if (PAD == 2) return ST == 3 ? 16 : ((ST == 7 || ST == 8) ? 15 : (ST == 16 ? 13 : 8));
     return ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8) ? 13 : (ST == 12 ? 9 : 8));
 }
 // position (0..15 within its block) that lane l15 works on

@@ -293,6 +293,12 @@ int pick_halo_cfg(const ConvParams& p, int mode)
             return CFG_H_128x64;
         return CFG_H_128x128;
     }
+    // 64 output channels at 128x128 or more (G's last up block, F's first down block): 256-position tiles (16x16), two position waves x two
+    // channel waves - a wave tile of 128 positions halves the weight bytes per MFMA of the 128x64 tile's 64-position wave tiles
+    // (CANONSWAP_UP256=0: A/B knob).  Same K order per output element; statistics per 16 x 4 positions as on every tile.
+    static const bool up256 = [] { const char* s = getenv("CANONSWAP_UP256"); return !s || atoi(s) != 0; }();
+    if (up256 && Cout_pad == 64 && (mode == MODE_STD || mode == MODE_STDSTAT) && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.Cin % 64 == 0 && p.cg == 0 &&
+        p.H % 16 == 0 && p.W % 16 == 0 && p.H >= 128 && !p.sk_out) return CFG_H_256x64;
     if (Cout_pad % 64 == 0) return CFG_H_128x64;
     if (Cout_pad % 32 == 0) return CFG_H_128x32;
     return CFG_H_128x16;

@@ -328,6 +328,38 @@ def test_conv_256x64_tile():
     assert torch.equal(outs[0], outs[1])        # same K order per output element: bit-identical across tile shapes
 
 
+@pytest.mark.parametrize("stat", [False, True])
+def test_conv_256x64_tile_2d(stat):
+    """3x3, 128 -> 64 (G's last up block / F's first down block) on the 2-D 256-position x 64-channel tile (16x16) against the 128x64
+    one: the same bits in the output, the same per-(16 x 4 positions) partial statistics (in another block order)."""
+    import hip_ops as ops
+    r = _rng(43)
+    N, Cin, Cout, S = 2, 128, 64, 32
+    x = _randn(r, N, Cin, S, S)
+    w = _randn(r, Cout, Cin, 3, 3, scale=1.0 / np.sqrt(Cin * 9))
+    b = _randn(r, Cout, scale=0.1)
+    res = _randn(r, N, Cout, S, S)
+    ref = _ref_conv(x.unsqueeze(2), w.unsqueeze(2), b, (0, 1, 1)) + res.half().float().unsqueeze(2)
+    wp = ops.packed_weight(w.unsqueeze(2), 64, DEV)
+    xd, rd = _to_cl(x).to(DEV), _to_cl(res).to(DEV)
+    outs, sums = [], []
+    for cfg in (11, 20):
+        out = torch.zeros(N, 1, S, S, 64, dtype=torch.float16, device=DEV)
+        nblk = S * S // 64
+        so = torch.zeros(N, nblk, 64, 2, dtype=torch.float32, device=DEV) if stat else None
+        ops.conv(xd, wp, 64, 64, (1, 3, 3), bias=b.to(DEV), res=rd, out0=out, cfg=cfg, tile=(16, 16) if cfg == 20 else (0, 0), stat_out=so)
+        torch.cuda.synchronize()
+        assert ops.rel_err(_from_cl(out), ref) < 3e-3
+        outs.append(out.cpu())
+        if stat:
+            sums.append(so.double().sum(1).cpu())
+    assert torch.equal(outs[0], outs[1])
+    if stat:
+        o = outs[0].double().reshape(N, S * S, 64)
+        assert torch.allclose(sums[0][..., 0], o.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(sums[1][..., 0], o.sum(1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(sums[0], sums[1], rtol=1e-6, atol=1e-4)
+
+
 @pytest.mark.parametrize("k,tile,cfg,cout_pad,cin_real,cin", [((3, 3, 3), (8, 8), 19, 160, 142, 144), ((7, 7, 1), (2, 8), 19, 160, 142, 144),
                                                               ((3, 3, 3), (8, 8), 20, 64, 110, 112)])
 def test_conv_ragged_last_chunk_paired_taps(k, tile, cfg, cout_pad, cin_real, cin):
