@@ -70,9 +70,14 @@ __device__ __forceinline__ void load4(const TDesc& t, int is_f32, long off, floa
 // The conversion is therefore written as the instruction the compiler uses anyway, where it cannot be folded into.
 __device__ __forceinline__ unsigned ep_pk(float a, float b)          // (fp16(a), fp16(b)) in one register
 {
+#ifdef EP_HOST_EMULATION          /* tests/epilogue_host: the macro executed on the host */
+    const half_t ha = (half_t)a, hb = (half_t)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+#else
     unsigned r;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#endif
 }
 __device__ __forceinline__ half_t ep_h(float v)
 {

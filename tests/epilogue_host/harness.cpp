@@ -20,9 +20,16 @@ static void cs_set_error(const char*, ...) {}
 static uint32_t hsh(uint32_t a) { a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16; return a; }
 static float rnd(uint32_t a) { return (float)(hsh(a) % 20001) / 10000.f - 1.f; }
 
+// EP_FAST as in conv_halo_kernel.h (the branch-free copies of the epilogue for the hot tensor combinations): HARNESS_NO_FAST runs
+// every case through the general path only; both builds must print the same checksums
 template <int WPX, int WCH, int WVP, int WVC, int MODE, bool EP_HEAVY>
 void run(const ConvParams& p, int BM)
 {
+#ifdef HARNESS_NO_FAST
+    constexpr bool EP_FAST = false;
+#else
+    constexpr bool EP_FAST = (WCH == 4 || WCH == 5 || (WCH == 2 && WPX == 8));
+#endif
     constexpr int BN = WCH * 16 * WVC;
     const int ntiles = p.nTW * p.nTH * p.nTD * p.nTN;
     for (int cb = 0; cb < p.Cout_pad / BN; ++cb)
@@ -207,6 +214,60 @@ int main()
             c0[v] = crc(out0.data(), out0.size() * 2); c1[v] = crc(st.data(), st.size() * 4);
         }
         printf("case8 %016llx %016llx same=%d\n", (unsigned long long)c0[0], (unsigned long long)c1[0], (int)(c0[0] == c0[1] && c1[0] == c1[1]));
+    }
+    // cases 9-12: the tensor combinations that have a branch-free copy (EP_FAST builds take it, HARNESS_NO_FAST builds the general path)
+    // case 9: SPADE 128x256, fp16 x at the same and at half resolution, every channel valid
+    for (int sh = 0; sh < 2; ++sh) {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 1; p.H = 16; p.W = 16; p.Cout = 256; p.Cout_pad = 512; tile_of(p, 128, 16, 8);
+        const int Sx = 16 >> sh;
+        const size_t P = (size_t)p.N * p.H * p.W, Px = (size_t)p.N * Sx * Sx;
+        auto x = H(Px * 256, 91); auto bias = F(256, 92), bias2 = F(256, 93), stats = F(p.N * 256 * 2, 94);
+        std::vector<half_t> out0(P * 256, (half_t)-9.f);
+        p.res = TDesc{x.data(), (long)Sx * Sx * 256, 0, (long)Sx * 256, 256}; p.res_f32 = 0; p.res_shift = sh;
+        p.out0 = TDesc{out0.data(), (long)p.H * p.W * 256, 0, (long)p.W * 256, 256};
+        p.bias = bias.data(); p.bias2 = bias2.data(); p.stats = stats.data(); p.act0 = ACT_LRELU; p.slope0 = 0.2f; p.ps_stride = 1;
+        run<8, 4, 1, 4, MODE_SPADE, false>(p, 128);
+        printf("case9.%d %016llx\n", sh, (unsigned long long)crc(out0.data(), out0.size() * 2));
+    }
+    // case 10: 128x256 and 128x128 STD / STDSTAT, fp16 output, without and with an fp16 residual
+    for (int v = 0; v < 4; ++v) {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 3; p.D = 1; p.H = 16; p.W = 32; p.Cout = 256; p.Cout_pad = 256; tile_of(p, 128, 16, 8);
+        const size_t P = (size_t)p.N * p.H * p.W;
+        auto bias = F(256, 101); auto res = H(P * 256, 102);
+        std::vector<half_t> out0(P * 256, (half_t)-9.f);
+        std::vector<float> st((size_t)p.N * (p.H * p.W / 64) * 256 * 2, -9.f);
+        if (v & 1) p.res = TDesc{res.data(), (long)p.H * p.W * 256, 0, (long)p.W * 256, 256};
+        p.out0 = TDesc{out0.data(), (long)p.H * p.W * 256, 0, (long)p.W * 256, 256};
+        p.bias = bias.data(); p.act0 = ACT_LRELU; p.slope0 = 0.2f; p.ps_stride = 1;
+        if (v & 2) { p.stat_out = st.data(); run<8, 4, 1, 4, MODE_STDSTAT, false>(p, 128); run<8, 2, 1, 4, MODE_STDSTAT, false>(p, 128); }
+        else { run<8, 4, 1, 4, MODE_STD, false>(p, 128); }
+        printf("case10.%d %016llx %016llx\n", v, (unsigned long long)crc(out0.data(), out0.size() * 2), (unsigned long long)crc(st.data(), st.size() * 4));
+    }
+    // case 11: 128x256 STD, fp32 residual stream in and out + fp16 copy through an affine and LeakyReLU (R's 2-D blocks)
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 1; p.H = 16; p.W = 16; p.Cout = 256; p.Cout_pad = 256; tile_of(p, 128, 16, 8);
+        const size_t P = (size_t)p.N * p.H * p.W;
+        auto res = F(P * 256, 111), bias = F(256, 112), s2 = F(256, 113), t2 = F(256, 114);
+        std::vector<float> out0(P * 256, -9.f); std::vector<half_t> out1(P * 256, (half_t)-9.f);
+        TDesc d{nullptr, (long)p.H * p.W * 256, 0, (long)p.W * 256, 256};
+        p.res = d; p.res.p = res.data(); p.res_f32 = 1; p.out0 = d; p.out0.p = out0.data(); p.out0_f32 = 1; p.out1 = d; p.out1.p = out1.data();
+        p.bias = bias.data(); p.s2 = s2.data(); p.t2 = t2.data(); p.act1 = ACT_LRELU; p.slope1 = 0.01f; p.ps_stride = 1;
+        run<8, 4, 1, 4, MODE_STD, false>(p, 128);
+        printf("case11 %016llx %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 4), (unsigned long long)crc(out1.data(), out1.size() * 2));
+    }
+    // case 12: 256x160 volume tile (8x8x4), 144 of 160 channels (the second channel wave takes the ragged copy), fp16 output, ReLU
+    {
+        ConvParams p; memset(&p, 0, sizeof p);
+        p.N = 2; p.D = 8; p.H = 8; p.W = 8; p.Cout = 144; p.Cout_pad = 160; tile_of(p, 256, 8, 8);
+        const size_t V = (size_t)p.N * p.D * p.H * p.W;
+        auto bias = F(160, 121); std::vector<half_t> out0(V * 144, (half_t)-9.f);
+        p.out0 = TDesc{out0.data(), (long)p.D * p.H * p.W * 144, (long)p.H * p.W * 144, (long)p.W * 144, 144};
+        p.bias = bias.data(); p.act0 = ACT_RELU; p.ps_stride = 1;
+        run<8, 5, 2, 2, MODE_STD, false>(p, 256);
+        printf("case12 %016llx\n", (unsigned long long)crc(out0.data(), out0.size() * 2));
     }
     return 0;
 }
