@@ -18,7 +18,7 @@ enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 
        CFG_H_SK128x32 = 16 /* 4 waves split the K-steps, reduce through LDS */, CFG_H_128x256 = 17,
        CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */,
        CFG_H_256x160 = 19 /* 2x2 waves of 128 positions x 80 channels, one workgroup per CU: half the weight bytes per MFMA of 128x160 */,
-       CFG_H_256x64 = 20 /* 2x2 waves of 128 positions x 32 channels (3x3x3, 8x8x4 tiles): the same for the 64-channel hourglass blocks */,
+       CFG_H_256x64 = 20 /* 2x2 waves of 128 positions x 32 channels: 3x3x3 on 8x8x4 tiles (the 64-channel hourglass block) and 3x3 on 16x16 tiles (the 64-channel convs of G's last up block) */,
        CFG_VOL32 = 30 /* vol32.hip (cs_op_conv: force that kernel) */ };
 
 // A channels-last tensor view: element strides, channel stride is 1.
