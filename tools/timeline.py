@@ -53,6 +53,8 @@ def cases(B, r):
                                 pixscale=torch.rand(B * 4096 * 4, device=DEV), ps_stride=4, res=rn(B, 1, 64, 64, 512, dtype=np.float32),
                                 out0=torch.empty(B, 1, 64, 64, 512, dtype=torch.float32, device=DEV),
                                 out1=torch.empty(B, 1, 64, 64, 512, dtype=torch.float16, device=DEV), cfg=17), 144, 8 * 4, 2))
+    out.append(("T.mask", dict(x=x2, w=wgt(512, 16, (1, 3, 3)), cout_pad=16, cout=4, k=(1, 3, 3), bias=rn(4, dtype=np.float32), act0="sigmoid",
+                               out0=torch.empty(B, 1, 64, 64, 4, dtype=torch.float32, device=DEV), cfg=14), 144, 2 * 1, 3))
     # G 3x3 512->512 with residual
     out.append(("G.c512", dict(x=x2, w=wgt(512, 512, (1, 3, 3)), cout_pad=512, cout=512, k=(1, 3, 3), bias=rn(512, dtype=np.float32),
                                res=rn(B, 1, 64, 64, 512), out0=torch.empty(B, 1, 64, 64, 512, dtype=torch.float16, device=DEV), cfg=10), 144, 8 * 2, 3))
