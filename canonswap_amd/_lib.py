@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_unpack_u8", "cs_soft_erosion", "cs_prepare_crops", "cs_warp_affine_u8", "cs_warp_affine_f32", "cs_paste_back",
     "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
-    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged", "cs_op_resblock3d",
+    "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged", "cs_op_resblock3d", "cs_op_t_mask",
 ]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
@@ -244,6 +244,7 @@ def load():
     lib.cs_op_grid_sample3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     lib.cs_op_chan_stats.argtypes = [vp, ci, ci, C.c_long, ci, cf, vp, vp, vp]
     lib.cs_op_pair_ragged.argtypes = [vp, ci, ci, ci, ci, ci, vp]
+    lib.cs_op_t_mask.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp]
     lib.cs_op_resblock3d.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, cf, vp]
     lib.cs_op_chan_stats_partial_floats.argtypes = [ci, C.c_long, ci]
     lib.cs_op_chan_stats_partial_floats.restype = C.c_long

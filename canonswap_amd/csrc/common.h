@@ -194,6 +194,7 @@ int launch_ncdhw_to_hwdc(const float* in, float* out32, half_t* out16, const flo
 int launch_hwdc_to_ncdhw(const float* in, float* out, int N, int C, int D, int H, int W, hipStream_t st);
 int launch_nchw_to_nhwc16(const float* in, half_t* out, int N, int C, int HW, hipStream_t st);
 int launch_nhwc16_to_nchw(const half_t* in, float* out, int N, int C, int HW, hipStream_t st);
+int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, float* tmask, int N, int H, int W, hipStream_t st);
 int launch_t_style(const float* id, const float* fc, float* style, int nlayers, hipStream_t st);
 int launch_t_modulate(const float* wraw, const float* style, half_t* packed, int layer, hipStream_t st);
 int launch_pack_u8(const float* img, uint8_t* out, int N, int C, int H, int W, hipStream_t st);

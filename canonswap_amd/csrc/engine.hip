@@ -639,10 +639,19 @@ int run_T(cs_engine* e, int B, const int* slots, int* cur, hipStream_t st)
         for (int j = 0; j < 2; ++j) {   // ResnetBlock_Adaptive2D: conv1 -> ReLU -> conv2, + x (:337-349)
             TLayer& L = e->t_l[i * 2 + j];
             const half_t* in = e->va[j];
-            ConvCall mc = mk(L.mask, in, hwdc2(nullptr), B, 1, 64, 64);       // mask_conv + sigmoid (:118-121,176)
-            mc.p.act0 = ACT_SIGMOID;
-            mc.p.out0 = td(e->tmask, 4096L * 4, 0, 64 * 4, 4); mc.p.out0_f32 = 1;
-            TRY(go(e, mc, st));
+            // mask_conv + sigmoid (:118-121,176): 512 -> 1 channel, a memory-bound dot product - its own VALU kernel (t_mask_kernel: 65 -> 4x us
+            // per launch against one row of sixteen on the MFMA kernel; CANONSWAP_TMASK_VALU=0: A/B knob, another summation order)
+            static const bool tmask_valu = [] { const char* s = getenv("CANONSWAP_TMASK_VALU"); return !s || atoi(s) != 0; }();
+            if (tmask_valu) {
+                const double mfl = 2.0 * L.mask.macs_per_pos * (double)B * 4096;
+                e->flops += mfl; e->flops_exec += mfl;
+                TRY(e->run(0, st, [&] { return launch_t_mask(in, L.mask.w, L.mask.b, e->tmask, B, 64, 64, st); }, L.mask.name.c_str(), mfl));
+            } else {
+                ConvCall mc = mk(L.mask, in, hwdc2(nullptr), B, 1, 64, 64);
+                mc.p.act0 = ACT_SIGMOID;
+                mc.p.out0 = td(e->tmask, 4096L * 4, 0, 64 * 4, 4); mc.p.out0_f32 = 1;
+                TRY(go(e, mc, st));
+            }
             ConvCall fc = mk(L.fused, in, hwdc2(nullptr), B, 1, 64, 64);      // [W ; w_mod] fused, blend epilogue
             fc.mode = MODE_TBLEND;
             if (mixed) { fc.p.wgt = L.wset[0]; fc.p.wofs = L.wofs; fc.p.wslot = e->slot_dev; }   // per-sample w_mod (groups=N, :157-167)
@@ -1563,6 +1572,11 @@ extern "C" int cs_op_resblock3d(const void* a, const float* x, float* out0, void
     c.w1 = (const half_t*)w1; c.w2 = (const half_t*)w2; c.b1 = b1; c.b2 = b2; c.s2 = s2; c.t2 = t2; c.act1 = act1; c.slope1 = slope1;
     c.N = N; c.H = H; c.W = W;
     return launch_vol32_fused(c, (hipStream_t)stream);
+}
+
+extern "C" int cs_op_t_mask(const void* x, const void* wpacked, const float* bias, float* tmask, int N, int H, int W, void* stream)
+{
+    return launch_t_mask((const half_t*)x, (const half_t*)wpacked, bias, tmask, N, H, W, (hipStream_t)stream);
 }
 
 extern "C" int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream)

@@ -821,6 +821,99 @@ __global__ void __launch_bounds__(512) t_style_kernel(const float* __restrict__ 
     style[(long)blockIdx.x * 512 + j] = b;
 }
 
+// T's mask conv (adaptive_modulate.py:118-121,176: 3x3 conv 512 -> 1 + sigmoid on the 64x64 feature map) as a VALU kernel.  On the
+// MFMA conv kernel this layer uses one of sixteen output rows and is bound by per-chunk latencies (65 us for 134 MB at 32 frames, 14
+// launches per frame batch); it is a memory-bound dot product.  Layout x [N][H][W][512] fp16: a lane owns 8 channels (one 16-byte load
+// per position: a wave reads a position's 1 KiB in one instruction), a wave owns SEG = 16 output positions of one row and streams the
+// 3 x 18 input positions that reach them; every input position feeds the three outputs w - 1 .. w + 1 of its row offset (9 taps x 4
+// v_dot2_f32_f16 with the lane's 72 weights in registers).  The 16 per-lane partial sums are reduced over the 64 lanes by recursive
+// halving (17 exchanges; a fixed order).  Weights are read from the conv packing [j * 9 + tap][16][32] (row 0, j = channel / 32).
+// out: tmask[(n * H * W + h * W + w) * 4] = sigmoid(sum + bias[0]) (the blend epilogue reads it at stride 4).
+typedef _Float16 tm_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tm_dot8(const uint4& v, const uint4& q, float a)
+{
+    a = __builtin_amdgcn_fdot2(__builtin_bit_cast(tm_h2, v.x), __builtin_bit_cast(tm_h2, q.x), a, false);
+    a = __builtin_amdgcn_fdot2(__builtin_bit_cast(tm_h2, v.y), __builtin_bit_cast(tm_h2, q.y), a, false);
+    a = __builtin_amdgcn_fdot2(__builtin_bit_cast(tm_h2, v.z), __builtin_bit_cast(tm_h2, q.z), a, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(tm_h2, v.w), __builtin_bit_cast(tm_h2, q.w), a, false);
+}
+__global__ void __launch_bounds__(256, 4) t_mask_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp, const float* __restrict__ bias,
+                                                        float* __restrict__ tmask, int N, int H, int W)
+{
+    constexpr int SEG = 16, RS = 65;                        // LDS row stride 65 floats: the reduction's reads are conflict-free
+    __shared__ float part[4][SEG * RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = W / SEG;
+    // XCD-aware order: hardware places workgroup b on XCD b % 8; every XCD walks a contiguous range of rows (the three input rows of
+    // neighbouring output rows are then fetched into one L2)
+    long blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long item = blk * 4 + wave;                       // (n, h, segment); the launcher makes the item count a multiple of 4
+    const int sg = (int)(item % nseg); long r = item / nseg;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const int w0 = sg * SEG;
+    // this lane's weights: tap t, channels lane * 8 .. + 7 = packed chunk j = lane / 4, k = (lane % 4) * 8
+    uint4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *(const uint4*)(wp + ((long)((lane >> 2) * 9 + t) * 16) * 32 + (lane & 3) * 8);
+    const half_t* xb = x + (long)n * H * W * 512 + lane * 8;
+    const bool hok0 = h > 0, hok2 = h + 1 < H;
+    const long r0 = (long)(hok0 ? h - 1 : h) * W, r1 = (long)h * W, r2 = (long)(hok2 ? h + 1 : h) * W;
+    auto fetch = [&](int c, uint4 (&v)[3]) {               // input column w0 - 1 + c of the three rows (zero outside the map)
+        const int wi = w0 - 1 + c;
+        const bool cin = (unsigned)wi < (unsigned)W;
+        const int wq = cin ? wi : w0;
+        v[0] = *(const uint4*)(xb + (r0 + wq) * 512);
+        v[1] = *(const uint4*)(xb + (r1 + wq) * 512);
+        v[2] = *(const uint4*)(xb + (r2 + wq) * 512);
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        if (!cin || !hok0) v[0] = z;
+        if (!cin) v[1] = z;
+        if (!cin || !hok2) v[2] = z;
+    };
+    // rolling accumulators: a2 = output c (kw = 0 so far), a1 = output c - 1, a0 = output c - 2 (complete after this column)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    uint4 cur[3], nxt[3];
+    fetch(0, cur);
+#pragma unroll 2
+    for (int c = 0; c < SEG + 2; ++c) {
+        if (c + 1 < SEG + 2) fetch(c + 1, nxt);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            a2 = tm_dot8(cur[kh], wt[kh * 3 + 0], a2);
+            a1 = tm_dot8(cur[kh], wt[kh * 3 + 1], a1);
+            a0 = tm_dot8(cur[kh], wt[kh * 3 + 2], a0);
+        }
+        if (c >= 2) part[wave][(c - 2) * RS + lane] = a0;
+        a0 = a1; a1 = a2; a2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cur[k] = nxt[k];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes (no other wave reads them)
+    // lane = output o (lane / 4), quarter q of the 64 channel lanes: 16 partials in a fixed order, then the four quarters
+    const int o = lane >> 2, q = lane & 3;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += part[wave][o * RS + q * 16 + i];
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    if (q == 0) {
+        const float y = sum + bias[0];
+        tmask[(((long)n * H + h) * W + w0 + o) * 4] = 1.f / (1.f + __expf(-y));
+    }
+}
+
+int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, float* tmask, int N, int H, int W, hipStream_t st)
+{
+    if (W % 16 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)wpacked & 15)) { cs_set_error("t_mask: width a multiple of 16, 16-byte aligned tensors"); return -1; }
+    const long items = (long)N * H * (W / 16);
+    if (items % 4 != 0) { cs_set_error("t_mask: N * H * W / 16 must be a multiple of 4"); return -1; }
+    hipLaunchKernelGGL(t_mask_kernel, dim3((unsigned)cdiv(items, 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
+    LAUNCH_CHECK("t_mask");
+    return 0;
+}
+
 int launch_t_style(const float* id, const float* fc, float* style, int nlayers, hipStream_t st)
 {
     hipLaunchKernelGGL(t_style_kernel, dim3(nlayers), dim3(512), 0, st, id, fc, style);

@@ -156,6 +156,9 @@ int cs_op_conv(const cs_conv_desc* d, void* stream);
  * taps that are neighbours along the row share one 32-deep K-step (what the engine does for the hourglass tail, the mask conv and the
  * first encoder block at load time; dense_motion.py:88, util.py:185-190,261-263) */
 int cs_op_pair_ragged(void* w, int Cout_pad, int nchunks, int KD, int KH, int KW, void* stream);
+/* T's mask conv + sigmoid (adaptive_modulate.py:118-121,176: Conv2d(512, 1, 3, padding 1)) as a memory-bound VALU kernel: x fp16 [N][H][W][512],
+ * w the layer's packed conv weight [16 chunks * 9 taps][16][32] (row 0 is the output channel), tmask[(n H W + h W + w) * 4] = sigmoid(conv + bias[0]) */
+int cs_op_t_mask(const void* x, const void* wpacked, const float* bias, float* tmask, int N, int H, int W, void* stream);
 /* one ResBlock3d of a feature volume (util.py:80-102, BatchNorms folded): contiguous [N][H][W][16][32] volumes a (fp16), x (fp32) ->
  * out0 (fp32) = conv2(relu(conv1(a) + b1)) + b2 + x, out1 (fp16) = act1(out0 * s2 + t2); w1 / w2 packed like every 3x3x3 32 -> 32 weight */
 int cs_op_resblock3d(const void* a, const float* x, float* out0, void* out1, int N, int H, int W, const void* w1, const void* w2,

@@ -75,6 +75,16 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
     _lib.check(lib.cs_op_conv(C.byref(d), st), "cs_op_conv")
 
 
+def t_mask(x, wpacked, bias):
+    """x: [N, H, W, 512] fp16 -> sigmoid(conv3x3(x) + bias[0]) as [N, H, W] fp32 (cs_op_t_mask writes at stride 4)"""
+    lib = _lib.load()
+    N, H, W, _ = x.shape
+    out = torch.full((N, H, W, 4), -1.0, dtype=torch.float32, device=x.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.cs_op_t_mask(_p(x), _p(wpacked), _p(bias), _p(out), N, H, W, st), "cs_op_t_mask")
+    return out
+
+
 def pair_ragged(wpacked, cout_pad, cin, k):
     """In place: the engine's load-time re-packing of the last chunk of a Cin % 32 == 16 layer (paired taps)."""
     lib = _lib.load()

@@ -328,6 +328,28 @@ def test_conv_256x64_tile():
     assert torch.equal(outs[0], outs[1])        # same K order per output element: bit-identical across tile shapes
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 64), (3, 16, 32), (1, 4, 16)])
+def test_t_mask_valu_kernel(N, H, W):
+    """T's mask conv (512 -> 1, 3x3, sigmoid) on its VALU kernel against torch and against the same layer on the MFMA conv kernel
+    (another summation order: 1e-5 on the gate); only element 0 of each group of four is written."""
+    import hip_ops as ops
+    r = _rng(77 + H)
+    x = F.relu(_randn(r, N, 512, H, W))
+    w = _randn(r, 1, 512, 3, 3, scale=2.0 / np.sqrt(512 * 9))
+    b = _randn(r, 4, scale=0.1)
+    ref = torch.sigmoid(F.conv2d(x.half().float(), w.half().float(), b[:1], padding=1))[:, 0]
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    wp = ops.packed_weight(w.unsqueeze(2), 16, DEV)
+    out = ops.t_mask(xd, wp, b.to(DEV))
+    torch.cuda.synchronize()
+    assert float((out[..., 0].cpu() - ref).abs().max()) < 2e-5
+    assert float((out[..., 1:] + 1.0).abs().max()) == 0.0
+    halo = torch.zeros(N, 1, H, W, 4, dtype=torch.float32, device=DEV)
+    ops.conv(xd.unsqueeze(1), wp, 16, 4, (1, 3, 3), bias=b.to(DEV), act0="sigmoid", out0=halo, cfg=14)
+    torch.cuda.synchronize()
+    assert float((out[..., 0] - halo[:, 0, ..., 0]).abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("stat", [False, True])
 def test_conv_256x64_tile_2d(stat):
     """3x3, 128 -> 64 (G's last up block / F's first down block) on the 2-D 256-position x 64-channel tile (16x16) against the 128x64
