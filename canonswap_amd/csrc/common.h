@@ -177,6 +177,7 @@ int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, c
 int launch_dm_softmax_warp(const float* part, const float* bias, const float* kp_d, const float* kp_s, const float* in, float* out32,
                            half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact = 0);
 int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
+int launch_occ_finish49(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
 int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);
 int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st);
 long chan_stats_partial_floats(int N, long P, int C);

@@ -71,7 +71,7 @@ struct cs_engine {
     Affine f_pre0;
     struct RB3 { ConvL c1, c2; Affine post; } f_rb[6], t_rb[6];
     const float *cmp_w = nullptr, *cmp_b = nullptr;
-    ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_occ, w_third, w_fourth;
+    ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_occ, w_occ49, w_third, w_fourth;
     ConvL w_dec_p[2][4];                   // up-blocks 3 and 4 per output phase (a, b) on the source grid
     float occ_b = 0.f;
     const float* mask_b = nullptr;
@@ -590,6 +590,19 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose
     // input channels are grouped by depth slice (16 groups of 144 channels at stride sD) and whose 7 output channels are the
     // 7 horizontal taps (summed by occ_finish_kernel).
+    // Batched path (CANONSWAP_OCC49=0: A/B knob): the taps move into the output channels altogether - a 1x1 conv over the same grouped
+    // channels with 49 (ky, kx) output channels (64 packed), finished by occ_finish49_kernel.  The (7,1)-tap form reads every activation
+    // from LDS seven times for 7 useful output rows of 32 and was bound by exactly that (0.37 ms per call at 32 frames for 604 MB).
+    static const bool occ49 = [] { const char* s = getenv("CANONSWAP_OCC49"); return !s || atoi(s) != 0; }();
+    if (occ49 && !e->latency_mode) {
+        ConvCall oc = mk(e->w_occ49, e->dm_pred, td(nullptr, (long)FD * 4096 * 144, 0, 64L * 144, 144), B, 1, 64, 64);
+        oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
+        oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 64); oc.p.out0_f32 = 1;
+        oc.hcfg = CFG_H_128x64;
+        TRY(go(e, oc, st));
+        TRY(e->run(1, st, [&] { return launch_occ_finish49(e->dm_occpart, e->occ_b, e->dm_occ, B, 64, 64, st); }, "occ_finish"));
+        return 0;
+    }
     ConvCall oc = mk(e->w_occ, e->dm_pred, td(nullptr, (long)FD * 4096 * 144, 0, 64L * 144, 144), B, 1, 64, 64);
     oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
     oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 16); oc.p.out0_f32 = 1;
@@ -1010,7 +1023,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     CS_CHECK_HIP(hipHostMalloc((void**)&e->slot_pin, sizeof(int) * 16 * B));
     e->stats_slots = 48; e->stats_slot_floats = B * 512 * 2;
     A(stats_pool, e->stats_slots * e->stats_slot_floats);
-    A(stats_part, B * 262144); A(dm_occpart, B * 4096 * 16);
+    A(stats_part, B * 262144); A(dm_occpart, B * 4096 * 64);
     for (int i = 0; i < 2; ++i) A(g_x[i], B * 4096 * 512);
     A(g_h64, B * 4096 * 512); A(g_dx64, B * 4096 * 512); A(g_a64, B * 4096 * 1536);
     A(g_a128, B * 16384 * 384); A(g_a256, B * 65536 * 384);
@@ -1131,6 +1144,7 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     }
     TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
     TRY(get_conv(e, "W.occp", 16 * 160, 32, 16, 1, 7, 1, 0, 2272.0 * 49, &e->w_occ));
+    TRY(get_conv(e, "W.occ49", 16 * 160, 64, 64, 1, 1, 1, 0, 2272.0 * 49, &e->w_occ49));
     { const Blob* b = e->find("W.occ.b"); if (!b || b->bytes != 4) { cs_set_error("weights: W.occ.b missing"); return -1; }
       CS_CHECK_HIP(hipMemcpy(&e->occ_b, b->p, 4, hipMemcpyDeviceToHost)); }
     TRY(get_conv(e, "W.third", 512, 256, 256, 1, 3, 3, 256, 512.0 * 256 * 9, &e->w_third));

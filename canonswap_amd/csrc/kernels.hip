@@ -438,6 +438,36 @@ __global__ void __launch_bounds__(256) occ_finish_kernel(const float* __restrict
     occ[i] = 1.f / (1.f + __expf(-s));
 }
 
+// the same for the 49-tap form (run_dense_motion): part[n][y][x][ky * 7 + kx] (row stride 64 floats) = the 1x1 conv of input position
+// (y, x) with tap (ky, kx); occ[y][x] = sigmoid(bias + sum_ky sum_kx part[y + ky - 3][x + kx - 3][ky * 7 + kx]), zero padding, fixed order
+__global__ void __launch_bounds__(256) occ_finish49_kernel(const float* __restrict__ part, float bias, float* __restrict__ occ, int N, int H, int W)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * H * W) return;
+    const int x = i % W, y = (i / W) % H;
+    float s = bias;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+        const int yy = y + ky - 3;
+        const bool yok = (unsigned)yy < (unsigned)H;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const int xx = x + kx - 3;
+            const bool ok = yok && (unsigned)xx < (unsigned)W;
+            const float v = part[(ok ? i + (long)(ky - 3) * W + (kx - 3) : i) * 64 + ky * 7 + kx];
+            s += ok ? v : 0.f;
+        }
+    }
+    occ[i] = 1.f / (1.f + __expf(-s));
+}
+
+int launch_occ_finish49(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st)
+{
+    hipLaunchKernelGGL(occ_finish49_kernel, dim3(cdiv((long)N * H * W, 256)), dim3(256), 0, st, part, bias, occ, N, H, W);
+    LAUNCH_CHECK("occ_finish49");
+    return 0;
+}
+
 int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st)
 {
     hipLaunchKernelGGL(occ_finish_kernel, dim3(cdiv((long)N * H * W, 256)), dim3(256), 0, st, part, bias, occ, N, H, W);

@@ -148,6 +148,12 @@ def _pack_W(out, sd):
     wg = np.zeros((7, 16, 160, 7, 1), np.float32)
     wg[:, :, :142, :, 0] = wo.transpose(3, 1, 0, 2)                  # [kx][d][c][ky]
     out["W.occp.w"] = pack_conv(wg.reshape(7, 16 * 160, 7, 1), 32)
+    # second form (batched path): a 1x1 conv over the same grouped channels with the 49 taps as output channels,
+    #   w49[ky*7 + kx][d*160 + c] = W_occ[0][c*16 + d][ky][kx]
+    # - no halo, every activation read from LDS once for all taps; occ_finish49_kernel adds the 49 shifted partials
+    w49 = np.zeros((49, 16, 160), np.float32)
+    w49[:, :, :142] = wo.transpose(2, 3, 1, 0).reshape(49, 16, 142)   # [ky][kx][d][c]
+    out["W.occ49.w"] = pack_conv(w49.reshape(49, 16 * 160, 1, 1), 64)
     out["W.occ.b"] = _f32(sd[p + ".occlusion.bias"].reshape(1))
     s, t = bn_affine(sd, "third.norm")
     w, b = fold_conv_bn(sd["third.conv.weight"][:, MEM2REF], sd["third.conv.bias"], s, t)

@@ -54,7 +54,7 @@ def test_view_permutation_is_the_reference_view():
 def test_build_blobs_names_and_sizes(state_dicts_np):
     blobs = pack.build_blobs(state_dicts_np)
     assert blobs["T.b6.c2.w"].shape == (144, 1024, 32) and blobs["T.b0.c1.raw"].shape == (512, 9, 512)
-    assert blobs["W.maskp.w"].shape == (5 * 49, 160, 32) and blobs["W.occp.w"].shape == (80 * 7, 32, 32)
+    assert blobs["W.maskp.w"].shape == (5 * 49, 160, 32) and blobs["W.occp.w"].shape == (80 * 7, 32, 32) and blobs["W.occ49.w"].shape == (80, 64, 32)
     assert blobs["G.shared64.w"].shape == (72, 1536, 32) and blobs["G.up1.n1.w"].shape == (36, 128, 32)
     assert all(b.flags["C_CONTIGUOUS"] for b in blobs.values())
     # every blob the engine asks for by literal name exists (names built with snprintf are covered on the GPU)
