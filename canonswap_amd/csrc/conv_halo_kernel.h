@@ -332,11 +332,16 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         // the chunk index: behind the last chunk the fetches repeat its first steps and are dropped).  The ragged chunk has another step
         // count, but it is the last one.  Hourglass tail and first encoder block -4 %, +0.25 % on the step; with two or three waves per
         // SIMD the others fill that gap already and the longer live ranges cost the 128x256 kernels 12-24 bytes of scratch: -0.2 %
-        // (profiles/r03_n_ab_wcarry.txt; -DCS_NO_WCARRY is the A/B switch).  The mask conv's 49 steps are not a multiple of 3.
+        // (profiles/r03_n_ab_wcarry.txt; -DCS_NO_WCARRY is the A/B switch).  Where a chunk is not a whole number of ring turns (the mask conv:
+        // 49 steps) the slot a step s of the last turn frees takes the next chunk's step s % PFS - the step that slot serves there.
 #ifdef CS_NO_WCARRY
         constexpr bool WCARRY = false;
 #else
+#ifdef CS_WCARRY_MULT
         constexpr bool WCARRY = (NS % PFS == 0) && NS >= 2 * PFS && WPX == 8 && WVP == 2;
+#else
+        constexpr bool WCARRY = NS >= 2 * PFS && WPX == 8 && WVP == 2;
+#endif
 #endif
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
         u4_t wr[PFS][WCH];
@@ -423,7 +428,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + ab_of(pi, st) + toff);
                 if (ILV && st >= 1) {
                     if (st - 1 + PFS < NSC) wload_at(wr[(st - 1) % PFS], cc, st - 1 + PFS);
-                    else if (WCARRY && !RAG) wload_at(wr[(st - 1) % PFS], cc + 1, st - 1 + PFS - NSC);
+                    else if (WCARRY && !RAG) wload_at(wr[(st - 1) % PFS], cc + 1, (st - 1) % PFS);
                 }
                 if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -458,10 +463,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ILV) {
                     if (st + PFS < NSC) wload_at(wr[st % PFS], cc, st + PFS);
-                    else if (WCARRY && !RAG) wload_at(wr[st % PFS], cc + 1, st + PFS - NSC);
+                    else if (WCARRY && !RAG) wload_at(wr[st % PFS], cc + 1, st % PFS);
                 }
             }
-            if (ILV && WCARRY && !RAG) wload_at(wr[(NSC - 1) % PFS], cc + 1, PFS - 1);
+            if (ILV && WCARRY && !RAG) wload_at(wr[(NSC - 1) % PFS], cc + 1, (NSC - 1) % PFS);
         };
         // the ragged chunk is peeled off the loop (inside it, the two bodies together cost the 160-wide kernels 500-650 bytes of scratch)
         const bool rag = RAGK && p.ragged && cc_hi == nck;
