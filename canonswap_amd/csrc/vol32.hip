@@ -100,8 +100,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // ready-made A fragments (54 KiB, linear in the lane index: conflict-free) and is read per tap - 10 LDS reads per 12 MFMAs in that pass,
 // 4 per 12 in the other two: the LDS runs at half its rate.
 // XF (transform staging, split-precision kernels only): 0 - the input is DMA-staged from a [hi | lo] fp16 volume;  1 - it is an fp32 volume,
-// split on the way into LDS;  2 - it is lrelu(GroupNorm(y) [+ res]) of fp32 volumes, computed, split and (interior columns, with xf_out)
-// written back while it is staged.  Raw rows travel global -> registers (one step ahead) -> VALU -> ds_write, spread over the MFMA groups
+// split on the way into LDS;  2 .. 5 - it is lrelu(GroupNorm(y) [+ res]) of fp32 volumes, computed, split and (with xf_out) written back
+// while it is staged (2 + (residual ? 1 : 0) + (write-back ? 2 : 0): compile-time variants, the staging code has no run-time branch).  Raw rows travel global -> registers (one step ahead) -> VALU -> ds_write, spread over the MFMA groups
 // of a step, where the VALU work hides under the matrix pipe.
 template <int EPI, bool SPLIT, int XF>
 __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
@@ -226,10 +226,11 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
         };
         // ---- transform staging (XF): thread t handles pieces idx = it * 256 + t of a row slab (640 pieces of 8 channels: column idx / 64, depth
         // (idx / 4) % 16, channel group idx % 4 = t % 4 - consecutive threads read consecutive 32 bytes)
-        float4 xr[XF ? 3 : 1][2], xs[XF == 2 ? 3 : 1][2];       // raw row in flight: y [, res]
-        float xsc[XF == 2 ? 8 : 1], xsh[XF == 2 ? 8 : 1];
+        constexpr bool XRES = XF >= 2 && ((XF - 2) & 1) != 0, XWB = XF >= 2 && ((XF - 2) & 2) != 0;     // kind 2 variants: + residual, + write-back
+        float4 xr[XF ? 3 : 1][2], xs[XRES ? 3 : 1][2];       // raw row in flight: y [, res]
+        float xsc[XF >= 2 ? 8 : 1], xsh[XF >= 2 ? 8 : 1];
         const int xq = tid & 3;
-        if constexpr (XF == 2) {
+        if constexpr (XF >= 2) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int c = xq * 8 + r;
@@ -244,67 +245,74 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
         if constexpr (XF != 0) {
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
-                const int idx = it * 256 + tid, col = idx >> 6, d = (idx >> 2) & 15;
+                // 640 pieces on 768 thread slots: the upper half of the third round repeats the lower half's pieces (the same loads, the same
+                // values to the same LDS and global addresses) - no test of the piece index inside the K loop
+                int idx = it * 256 + tid;
+                if (idx >= V_NC * 64) idx -= 128;
+                const int col = idx >> 6, d = (idx >> 2) & 15;
                 xoff[it] = n * p.xy_sN + (w0 - 1 + col) * p.xy_sW + d * 32 + xq * 8;
-                xcok[it] = idx < V_NC * 64 && (unsigned)(w0 - 1 + col) < (unsigned)p.W;
+                xcok[it] = (unsigned)(w0 - 1 + col) < (unsigned)p.W;
             }
         }
-        auto xf_load = [&](int r, int it) {       // raw piece it of row r -> registers (zeros outside the volume)
+        // Branch-free by construction: a fetch behind a bounds test makes hipcc drain vmcnt to 0 where the branches join (every load and
+        // store of the step), and a branch inside the MFMA groups ends the scheduling region the conversion is interleaved in.  Pieces
+        // outside the volume fetch a valid address of their own sample (first row and column of the strip) and are zeroed after the
+        // transform; their write-back goes to the zero page - as zeros.
+        const unsigned xsafe = (unsigned)(n * p.xy_sN + w0 * p.xy_sW + h0 * p.xy_sH + ((tid >> 2) & 15) * 32 + xq * 8);
+        auto xf_load = [&](int r, int it) {       // raw piece it of row r -> registers
             if constexpr (XF != 0) {
-                xr[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); xr[it][1] = xr[it][0];
-                if constexpr (XF == 2) { xs[it][0] = xr[it][0]; xs[it][1] = xr[it][0]; }
-                if (xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1) {
-                    const unsigned o = (unsigned)(xoff[it] + r * p.xy_sH);
-                    const float* y = p.xf_y + o;
-                    xr[it][0] = *(const float4*)y; xr[it][1] = *(const float4*)(y + 4);
-                    if constexpr (XF == 2) {
-                        if (p.xf_res) {
-                            const float* x = p.xf_res + o;
-                            xs[it][0] = *(const float4*)x; xs[it][1] = *(const float4*)(x + 4);
-                        }
-                    }
+                const bool okl = xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1;
+                const unsigned o = okl ? (unsigned)(xoff[it] + r * p.xy_sH) : xsafe;
+                const float* y = p.xf_y + o;
+                xr[it][0] = *(const float4*)y; xr[it][1] = *(const float4*)(y + 4);
+                if constexpr (XRES) {
+                    const float* x = p.xf_res + o;
+                    xs[it][0] = *(const float4*)x; xs[it][1] = *(const float4*)(x + 4);
                 }
             }
         };
-        auto xf_write = [&](int r, int slot, int it) {     // registers -> transform -> [hi | lo] images of ring slot `slot`
+        // part 0 / 1: the transform of channels 0..3 / 4..7 of the piece; part 2: split, ds_writes [, write-back]; part < 0: all of it.  In the
+        // K loop the three parts of a piece go into three consecutive MFMA groups: a wave issues about three VALU instructions in the
+        // shadow of one MFMA (one wave per SIMD), a whole piece (~110 instructions) inside one group of 12 MFMAs left the matrix pipe idle
+        // for half of it.
+        float xa[8];
+        auto xf_write = [&](int r, int slot, int it, int part) {     // registers -> transform -> [hi | lo] images of ring slot `slot`
             if constexpr (XF != 0) {
-                const int idx = it * 256 + tid;
-                if (idx < V_NC * 64) {
-                    const bool ok = xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1;
-                    float a[8];
+                int idx = it * 256 + tid;
+                if (idx >= V_NC * 64) idx -= 128;
+                const bool ok = xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float v = ((const float*)&xr[it][k >> 2])[k & 3];
-                        if constexpr (XF == 2) a[k] = gn_lrelu(v, xsc[k], xsh[k], ((const float*)&xs[it][k >> 2])[k & 3], p.xf_slope);
-                        else a[k] = v;
-                        if (!ok) a[k] = 0.f;                 // zero padding applies to the conv's input, i.e. after the transform
-                    }
-                    h8_t hi, lo;
+                for (int k = 0; k < 8; ++k) {
+                    if (part >= 0 && (k >> 2) != part) continue;
+                    const float v = ((const float*)&xr[it][k >> 2])[k & 3];
+                    if constexpr (XRES) xa[k] = gn_lrelu(v, xsc[k], xsh[k], ((const float*)&xs[it][k >> 2])[k & 3], p.xf_slope);
+                    else if constexpr (XF >= 2) xa[k] = gn_lrelu(v, xsc[k], xsh[k], 0.f, p.xf_slope);
+                    else xa[k] = v;
+                    if (!ok) xa[k] = 0.f;                // zero padding applies to the conv's input, i.e. after the transform
+                }
+                if (part >= 0 && part != 2) return;
+                h8_t hi, lo;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { hi[k] = (half_t)a[k]; lo[k] = (half_t)(a[k] - (float)hi[k]); }
-                    unsigned char* dst = smem + xq * QS + (idx >> 6) * V_CS + (((idx >> 2) & 15) + 1) * 16 + slot * V_RS;
-                    *(h8_t*)dst = hi; *(h8_t*)(dst + IMG) = lo;
-                    if constexpr (XF == 2) {
-                        // the transformed tensor is the new residual stream: every strip writes the rows and columns it owns
-                        const int col = idx >> 6;
-                        if (p.xf_out && ok && col >= 1 && col <= V_TW && r >= h0 && r < h1) {
-                            float* o = p.xf_out + (unsigned)(xoff[it] + r * p.xy_sH);
-                            *(float4*)o = make_float4(a[0], a[1], a[2], a[3]); *(float4*)(o + 4) = make_float4(a[4], a[5], a[6], a[7]);
-                        }
-                    }
+                for (int k = 0; k < 8; ++k) { hi[k] = (half_t)xa[k]; lo[k] = (half_t)(xa[k] - (float)hi[k]); }
+                unsigned char* dst = smem + xq * QS + (idx >> 6) * V_CS + (((idx >> 2) & 15) + 1) * 16 + slot * V_RS;
+                *(h8_t*)dst = hi; *(h8_t*)(dst + IMG) = lo;
+                if constexpr (XWB) {
+                    // the transformed tensor is the new residual stream.  Every strip writes all the pieces it staged: the halo columns and
+                    // rows are its neighbours' too, who write the same bits there (nobody reads xf_out during this launch)
+                    float* o = ok ? p.xf_out + (unsigned)(xoff[it] + r * p.xy_sH) : (float*)p.zero;
+                    *(float4*)o = make_float4(xa[0], xa[1], xa[2], xa[3]); *(float4*)(o + 4) = make_float4(xa[4], xa[5], xa[6], xa[7]);
                 }
             }
         };
         if constexpr (XF != 0) {
-            // rows h0 - 1, h0, h0 + 1 into slots 0 .. 2, then row h0 + 2 into the registers
+            // rows h0 - 1, h0, h0 + 1 into slots 0 .. 2 (row h + 2 is fetched, transformed and written within step h: no load result is
+            // carried over the loop's back-edge, where hipcc would drain vmcnt to 0 - the step's own stores included - at every step)
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
                 for (int it = 0; it < 3; ++it) xf_load(h0 - 1 + i, it);
 #pragma unroll
-                for (int it = 0; it < 3; ++it) xf_write(h0 - 1 + i, i, it);
+                for (int it = 0; it < 3; ++it) xf_write(h0 - 1 + i, i, it, -1);
             }
-#pragma unroll
-            for (int it = 0; it < 3; ++it) xf_load(h0 + 2, it);
         } else {
             // row h0 - 1 + i lives in slot i (mod RING) of this item
 #pragma unroll
@@ -374,6 +382,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
 #pragma unroll
                 for (int ci = 0; ci < 2; ++ci) acc[c][ci] = (f4_t){0.f, 0.f, 0.f, 0.f};
             constexpr int NG = SPLIT ? 27 : 9;
+            constexpr int XL0 = 4, XW0 = 17;       // transform staging: first load group, first conversion group (of NG = 27)
             h8_t fa[4], fb[4];
             h8_t wa[SPLIT ? 3 : 1][2], wb[SPLIT ? 3 : 1][2];           // W_lo fragments of a group (pass 1)
             // group sequence.  Plain: 9 (kd, kh) groups.  Split precision (the halo kernel's chunk order): three passes of 9
@@ -414,7 +423,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
 #ifndef V32_XF_NOIL
                 // transform staging: the conversion of piece G2 / 2 of row h + 2 (VALU + two ds_writes) shares the scheduling region of this
                 // group's MFMAs and is spread between them (below)
-                if constexpr (XF != 0) { if (G2 < 6 && (G2 & 1) == 0) xf_write(h + 2, sk, G2 >> 1); }
+                if constexpr (XF != 0) { if (G2 >= XW0 && G2 < XW0 + 9) xf_write(h + 2, sk, (G2 - XW0) / 3, (G2 - XW0) % 3); }
 #endif
                 if (G2 + 1 < NG) {
                     h8_t (&nxt)[4] = g_buf(G2 + 1) ? fb : fa;
@@ -439,7 +448,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 if (G2 + 1 < NG) {
                     const int nrd = (g_newb(G2 + 1) ? 4 : 0) + ((SPLIT && g_pass(G2 + 1) == 1) ? 6 : 0);
 #ifndef V32_XF_NOIL
-                    const bool conv_here = XF != 0 && G2 < 6 && (G2 & 1) == 0;
+                    const bool conv_here = XF != 0 && G2 >= XW0 && G2 < XW0 + 9;
 #else
                     const bool conv_here = false;
 #endif
@@ -447,7 +456,7 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                     for (int i = 0; i < 11; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
                         if (i < nrd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one DS read
-                        if (conv_here) __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);    // a dozen VALU instructions of the conversion
+                        if (conv_here) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // a few VALU instructions of the conversion
                     }
                 }
 #endif
@@ -468,14 +477,14 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
-                    // transform staging: row h + 2 (in registers since last step) -> slot sk after groups 0 / 2 / 4, the loads of row h + 3 after
-                    // groups 6 / 8 / 10, then the stores of row h - 1: every wait the compiler places at a conversion finds loads and stores that
-                    // are most of a step old
+                    // transform staging: the stores of row h - 1 first (groups 0 .. NS - 1), then the loads of row h + 2 (groups XL0, +2, +4), its
+                    // conversion into slot sk late in the step (groups XW0 .. XW0 + 8, three parts per piece): the only memory instructions
+                    // younger than a piece's loads at its conversion are the other pieces' loads and write-backs - the compiler counts them
 #ifdef V32_XF_NOIL
-                    if (G2 < 6 && (G2 & 1) == 0) xf_write(h + 2, sk, G2 >> 1);
+                    if (G2 >= XW0 && G2 < XW0 + 9) xf_write(h + 2, sk, (G2 - XW0) / 3, (G2 - XW0) % 3);
 #endif
-                    if (G2 >= 6 && G2 < 12 && (G2 & 1) == 0) xf_load(h + 3, (G2 - 6) >> 1);
-                    if (G2 >= 12 && G2 < 12 + NS && have) store_piece(G2 - 12);
+                    if (G2 < NS && have) store_piece(G2);
+                    if (G2 >= XL0 && G2 < XL0 + 6 && ((G2 - XL0) & 1) == 0) xf_load(h + 2, (G2 - XL0) >> 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #endif
@@ -652,7 +661,13 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     int r = -1;
     if (split) {
         if (epi != V_EPI_STAT) { cs_set_error("vol32: the split-precision kernel exists with the statistics epilogue only"); return -1; }
-        if (p.xf_kind == 2) r = go(vol32_kernel<V_EPI_STAT, true, 2>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+        if (p.xf_kind == 2) {       // compile-time variants: + residual, + write-back (no run-time test inside the K loop)
+            const int v = (p.xf_res.p ? 1 : 0) | (p.xf_out.p ? 2 : 0);
+            if (v == 0) r = go(vol32_kernel<V_EPI_STAT, true, 2>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+            else if (v == 1) r = go(vol32_kernel<V_EPI_STAT, true, 3>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+            else if (v == 2) r = go(vol32_kernel<V_EPI_STAT, true, 4>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+            else r = go(vol32_kernel<V_EPI_STAT, true, 5>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
+        }
         else if (p.xf_kind == 1) r = go(vol32_kernel<V_EPI_STAT, true, 1>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
         else r = go(vol32_kernel<V_EPI_STAT, true, 0>, VRing<true, V_EPI_STAT>::lds(V_EPI_STAT));
     } else {
