@@ -101,8 +101,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // 4 per 12 in the other two: the LDS runs at half its rate.
 // XF (transform staging, split-precision kernels only): 0 - the input is DMA-staged from a [hi | lo] fp16 volume;  1 - it is an fp32 volume,
 // split on the way into LDS;  2 .. 5 - it is lrelu(GroupNorm(y) [+ res]) of fp32 volumes, computed, split and (with xf_out) written back
-// while it is staged (2 + (residual ? 1 : 0) + (write-back ? 2 : 0): compile-time variants, the staging code has no run-time branch).  Raw rows travel global -> registers (one step ahead) -> VALU -> ds_write, spread over the MFMA groups
-// of a step, where the VALU work hides under the matrix pipe.
+// while it is staged (2 + (residual ? 1 : 0) + (write-back ? 2 : 0): compile-time variants, the staging code has no run-time branch).  Raw rows travel global -> registers -> VALU -> ds_write within one step (fetched early, converted late), spread
+// over the MFMA groups, where the VALU work hides under the matrix pipe.
 template <int EPI, bool SPLIT, int XF>
 __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
 {
