@@ -2,7 +2,8 @@
 
 Floating-point tolerance (BASELINE.json north_star): PSNR >= 50 dB on the 3x512x512 image in [0,1] against the
 fp32 CPU reference; intermediate feature tensors are checked by relative L2 error.  The engine computes with
-fp16 operands / fp32 accumulation (fp32 residual streams), so bit-exactness is not expected.
+fp16 operands / fp32 accumulation (fp32 residual streams), so bit-exactness is not expected.  The stage gates sit about 3x above
+the errors measured on the GPU (tools/stage_errors.py -> profiles/r03_t_stage_errors.txt), not at a generic tolerance.
 """
 import numpy as np
 import pytest
@@ -40,35 +41,35 @@ def test_extract_feature_3d(swapper, case):
     args, _, ref = case
     f = swapper.extract_feature_3d(args["img"].cuda())
     assert f.shape == (2, 32, 16, 64, 64) and f.dtype == torch.float32
-    assert _rel(f, ref["f_s"]) < 3e-3
+    assert _rel(f, ref["f_s"]) < 1e-3                       # measured 3.95e-4 (tools/stage_errors.py, three seeds)
 
 
 def test_warp(swapper, case):
     args, _, ref = case
     f_can, occ = swapper.warping_module.warp(ref["f_s"].cuda(), args["x_t"].cuda(), args["x_can"].cuda())
-    assert _rel(occ, ref["occ"]) < 5e-3
-    assert _rel(f_can, ref["f_can"]) < 5e-3
+    assert _rel(occ, ref["occ"]) < 6e-4                     # measured 1.3e-4 .. 1.9e-4
+    assert _rel(f_can, ref["f_can"]) < 3e-4                 # measured 0.7e-4 .. 1.0e-4
 
 
 def test_swap_module(swapper, case):
     _, idv, ref = case
     out = swapper.swap_module(ref["f_can"].cuda(), idv.cuda())
-    assert _rel(out, ref["f_swap"]) < 3e-3
+    assert _rel(out, ref["f_swap"]) < 1e-3                  # measured 3.2e-4 .. 3.5e-4
 
 
 def test_refine_module(swapper, case):
     _, _, ref = case
     out = swapper.refine_module(ref["f_swap"].cuda())
-    assert _rel(out, ref["f_ref"]) < 5e-3
+    assert _rel(out, ref["f_ref"]) < 6e-4                   # measured 2.0e-4 .. 2.1e-4 (split-precision GroupNorm convs)
 
 
 def test_warp_decode(swapper, case):
     from oracle import canonswap_ref as O
     args, _, ref = case
     ret = swapper.warp_decode(ref["f_ref"].cuda(), args["x_can"].cuda(), args["x_t"].cuda())
-    assert _rel(ret["deformation"], ref["deformation"]) < 2e-3
-    assert _rel(ret["occlusion_map"], ref["occ2"]) < 1e-2
-    assert O.psnr(ret["out"].cpu(), ref["out"]) >= PSNR_GATE
+    assert _rel(ret["deformation"], ref["deformation"]) < 3e-4     # measured 0.6e-4 .. 0.8e-4
+    assert _rel(ret["occlusion_map"], ref["occ2"]) < 3e-3          # measured 4.3e-4 .. 9.0e-4
+    assert O.psnr(ret["out"].cpu(), ref["out"]) >= 60.0                 # W.forward + G from oracle inputs: measured 64.9 .. 66.8 dB
 
 
 def test_conv_decode(swapper, case, state_dicts):
@@ -78,9 +79,9 @@ def test_conv_decode(swapper, case, state_dicts):
     assert O.psnr(img.cpu(), ref["rec_can"]) >= PSNR_GATE
     seg = swapper.warping_module.warp_out(ref["f_ref"].cuda(), ref["occ2"].cuda())
     with torch.no_grad():
-        assert _rel(seg, O.warp_out(state_dicts["warping_module"], ref["f_ref"], ref["occ2"])) < 5e-3
+        assert _rel(seg, O.warp_out(state_dicts["warping_module"], ref["f_ref"], ref["occ2"])) < 1.5e-3      # measured 4.7e-4
         seg_noocc = swapper.warping_module.warp_out(ref["f_ref"].cuda())
-        assert _rel(seg_noocc, O.warp_out(state_dicts["warping_module"], ref["f_ref"], None)) < 5e-3
+        assert _rel(seg_noocc, O.warp_out(state_dicts["warping_module"], ref["f_ref"], None)) < 1.5e-3
 
 
 def test_swap_frames_psnr_and_debug(swapper, case):
