@@ -1,5 +1,5 @@
 """GPU box: the measured error of every stage gate of tests/test_gpu_stages.py (relative L2 / PSNR against the fp32 CPU oracle), for three
-input seeds - the numbers the gates in that file are set from.   python tools/stage_errors.py > gpurun_out/stage_errors.txt"""
+input seeds - the numbers the gates in that file are set from.   python tests/stage_errors.py > gpurun_out/stage_errors.txt"""
 import os
 import sys
 
