@@ -46,7 +46,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "32")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CANONSWAP_BENCH_BATCH", "64")),
+                    help="frames per launch and GPU (default 64, the engine's maximum: +1.5 % frames/s over 32 - fewer, longer launches leave fewer "
+                         "idle workgroup slots at the head and tail of each kernel; profiles/r03_v_batch_sweep.txt)")
     ap.add_argument("--frames", type=int, default=0,
                     help="fixed-size job (BASELINE configs[3]: --frames 1200): one step = one pass over a video of this many frames, "
                          "sharded over the ranks in contiguous blocks (strong scaling). Default 0: every rank runs --batch frames "

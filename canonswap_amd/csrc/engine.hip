@@ -489,22 +489,34 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
     return 0;
 }
 
+// F's three 2-D convs (down_blocks.0 / .1, second: appearance_feature_extractor.py:41-44) with split-precision WEIGHTS: the packed weight holds
+// [W_hi | W_lo] along the input channels (pack._pack_F) and the launch reads the same activations for both halves (grouped chunks at group
+// stride 0), so out = W_hi x + W_lo x in one fp16 MFMA conv of twice the K.  The fp16 rounding of these three weight tensors alone cost the
+// frame more than any other stage's arithmetic except T's (tests/psnr_attrib.py and the CPU emulation in DESIGN section 3: 57.5 dB with only
+// these weights rounded, everything else exact); the three launches are 0.7 ms of a 125 ms step.  CANONSWAP_F_WSPLIT=0: W_hi only (the A/B knob).
+bool f_wsplit() { static const bool v = [] { const char* s = getenv("CANONSWAP_F_WSPLIT"); return !s || atoi(s) != 0; }(); return v; }
+static void wsplit_in(ConvCall& c, int cin_real)
+{
+    if (!f_wsplit()) return;
+    c.p.cg = cin_real / 32; c.p.cg_cin = cin_real; c.p.in_sG = 0;       // chunk j -> channels (j % cg) * 32 of the one input tensor
+}
+
 int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 {
     TRY(e->run(1, st, [&] { return launch_conv_first(img, e->first_w, e->first_b, e->f_t0, B, IMG, IMG, st); }, "conv_first"));
     e->flops += 2.0 * 3 * 64 * 9 * (double)B * IMG * IMG;
     ConvCall d0 = mk(e->f_down0, e->f_t0, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
-    d0.p.act0 = ACT_RELU; d0.p.out0 = nhwc(e->f_t1, 256, 256, 128);
+    d0.p.act0 = ACT_RELU; d0.p.out0 = nhwc(e->f_t1, 256, 256, 128); wsplit_in(d0, 64);
     TRY(go(e, d0, st));
     TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }, "avgpool"));
     ConvCall d1 = mk(e->f_down1, e->f_p0, nhwc(nullptr, 128, 128, 128), B, 1, 128, 128);
-    d1.p.act0 = ACT_RELU; d1.p.out0 = nhwc(e->f_t2, 128, 128, 256);
+    d1.p.act0 = ACT_RELU; d1.p.out0 = nhwc(e->f_t2, 128, 128, 256); wsplit_in(d1, 128);
     TRY(go(e, d1, st));
     TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }, "avgpool"));
     *cur = 0;
     ConvCall s = mk(e->f_second, e->f_p1, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);   // 1x1 -> the 32x16 volume
     s.p.out0 = hwdc2(e->vs[0]); s.p.out0_f32 = 1;
-    s.p.out1 = hwdc2(e->va[0]); s.p.s2 = e->f_pre0.s; s.p.t2 = e->f_pre0.t; s.p.act1 = ACT_RELU;
+    s.p.out1 = hwdc2(e->va[0]); s.p.s2 = e->f_pre0.s; s.p.t2 = e->f_pre0.t; s.p.act1 = ACT_RELU; wsplit_in(s, 256);
     TRY(go(e, s, st));
     return run_resblocks3d(e, e->f_rb, B, cur, nullptr, ACT_NONE, st);
 }
@@ -1102,9 +1114,11 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     }
     // ---- F
     TRY(get_f32(e, "F.first.w", 64 * 27, &e->first_w)); TRY(get_f32(e, "F.first.b", 64, &e->first_b));
-    TRY(get_conv(e, "F.down0", 64, 128, 128, 1, 3, 3, 128, 64.0 * 128 * 9, &e->f_down0));
-    TRY(get_conv(e, "F.down1", 128, 256, 256, 1, 3, 3, 256, 128.0 * 256 * 9, &e->f_down1));
-    TRY(get_conv(e, "F.second", 256, 512, 512, 1, 1, 1, 512, 256.0 * 512, &e->f_second));
+    // packed as [W_hi | W_lo] over twice the input channels (run_F: wsplit_in); with the knob off only the W_hi chunks (the first half) are used
+    TRY(get_conv(e, "F.down0", 128, 128, 128, 1, 3, 3, 128, 64.0 * 128 * 9, &e->f_down0));
+    TRY(get_conv(e, "F.down1", 256, 256, 256, 1, 3, 3, 256, 128.0 * 256 * 9, &e->f_down1));
+    TRY(get_conv(e, "F.second", 512, 512, 512, 1, 1, 1, 512, 256.0 * 512, &e->f_second));
+    if (!f_wsplit()) { e->f_down0.Cin = 64; e->f_down1.Cin = 128; e->f_second.Cin = 256; }
     TRY(get_affine(e, "F.pre0", 512, &e->f_pre0));
     for (int which = 0; which < 2; ++which) {
         cs_engine::RB3* rb = which ? e->t_rb : e->f_rb;

@@ -100,6 +100,15 @@ def _resblocks3d(out, prefix, sd):
     out[f"{prefix}.pre0.t"] = _f32(np.tile(t, 16))
 
 
+def _hi_lo(w):
+    """[Cout][Cin][...] -> [Cout][2 Cin][...] = [W_hi | W_lo] (both fp16-representable, W_hi + W_lo == W to 2^-22): split-precision weights for a
+    conv whose launch reads its input channels twice (engine.hip: wsplit_in), out = W_hi x + W_lo x."""
+    w = np.asarray(w, np.float64)
+    hi = w.astype(np.float16).astype(np.float64)
+    lo = (w - hi).astype(np.float16).astype(np.float64)
+    return np.concatenate([hi, lo], axis=1)
+
+
 def _pack_F(out, sd):
     s, t = bn_affine(sd, "first.norm")
     w, b = fold_conv_bn(sd["first.conv.weight"], sd["first.conv.bias"], s, t)
@@ -108,9 +117,9 @@ def _pack_F(out, sd):
     for i, (co) in enumerate((128, 256)):
         s, t = bn_affine(sd, f"down_blocks.{i}.norm")
         w, b = fold_conv_bn(sd[f"down_blocks.{i}.conv.weight"], sd[f"down_blocks.{i}.conv.bias"], s, t)
-        out[f"F.down{i}.w"] = pack_conv(w, co)
+        out[f"F.down{i}.w"] = pack_conv(_hi_lo(w), co)
         out[f"F.down{i}.b"] = _f32(b)
-    out["F.second.w"] = pack_conv(sd["second.weight"][MEM2REF], 512)
+    out["F.second.w"] = pack_conv(_hi_lo(sd["second.weight"][MEM2REF]), 512)
     out["F.second.b"] = _f32(sd["second.bias"][MEM2REF])
     _resblocks3d(out, "F", sd)
 

@@ -130,3 +130,19 @@ def test_min_psnr_over_32_frames_two_identities(swapper, state_dicts, batch):
     print(f"min PSNR over {B} frames x 2 identities: float {worst:.2f} dB, uint8 {worst8:.2f} dB, worst mean |diff| {mad:.3f} LSB")
     assert worst >= PSNR_GATE, worst
     assert worst8 >= 48.0 and mad < 0.6, (worst8, mad)
+
+
+def test_b64_frames_bit_equal_to_b32_and_b1(state_dicts, swapper, batch, out32):
+    """bench.py's default launch is 64 frames (the engine's maximum: 32-bit element offsets inside one tensor).  Frames 0 .. 31 of a 64-frame
+    call == the 32-frame call, frames 32 .. 63 (the same inputs again) == frames 0 .. 31, and frame 63 == that frame run alone: the batch
+    changes grid sizes and tile policy, never a frame's bits."""
+    from canonswap_amd.can_swap_e2e import can_swapper
+    args, idv = batch
+    sw64 = can_swapper(None, state_dicts=state_dicts, max_batch=64)
+    a64 = {k: torch.cat([v, v]).cuda() for k, v in args.items()}
+    r = sw64.swap_frames(a64["img"], a64["x_t"], a64["x_can"], idv.cuda(), want_u8=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r["out"].cpu()[:32], out32[0]) and torch.equal(r["out"].cpu()[32:], out32[0])
+    assert torch.equal(r["out_u8"].cpu()[:32], out32[1]) and torch.equal(r["out_u8"].cpu()[32:], out32[1])
+    one = swapper.swap_frames(args["img"][31:32].cuda(), args["x_t"][31:32].cuda(), args["x_can"][31:32].cuda(), idv.cuda(), want_u8=True)
+    assert torch.equal(one["out"].cpu()[0], r["out"].cpu()[63])

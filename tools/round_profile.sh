@@ -12,7 +12,8 @@ done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA -o pmc --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fixed-job > $OUT/pmc_MFMA.json 2> $OUT/pmc_MFMA.err
 cd /root/repo
 python tools/summarize_pmc.py $OUT > $OUT/pmc_summary.csv 2> $OUT/summarize.err
-python tools/summarize_pmc.py $OUT 32 $OUT/hbm_traffic.json 2>> $OUT/summarize.err
+BATCH=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['config']['frames_per_launch_per_gpu'])")
+python tools/summarize_pmc.py $OUT $BATCH $OUT/hbm_traffic.json 2>> $OUT/summarize.err
 python tools/reconcile_profile.py $(ls $OUT/stats/*kernel_stats.csv | head -1) $OUT/bench_profiled.json 43 > $OUT/reconcile.txt 2>> $OUT/summarize.err
 cat $OUT/reconcile.txt | head -8; cat $OUT/hbm_traffic.json
 # keep the merge-back under the gpurun limit: the raw counter dumps are large
