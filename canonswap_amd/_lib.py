@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "vol32.hip", "vol32_fused.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "conv_wide.hip", "vol32.hip", "vol32_fused.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
 # test-only cross-check kernel (the first-generation implicit-GEMM conv): its own library, never linked into the product
 TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "csrc", "test_igemm.hip")
 TEST_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcanonswap_test.so")

@@ -19,7 +19,7 @@ enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 
        CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */,
        CFG_H_256x160 = 19 /* 2x2 waves of 128 positions x 80 channels, one workgroup per CU: half the weight bytes per MFMA of 128x160 */,
        CFG_H_256x64 = 20 /* 2x2 waves of 128 positions x 32 channels: 3x3x3 on 8x8x4 tiles (the 64-channel hourglass block) and 3x3 on 16x16 tiles (the 64-channel convs of G's last up block) */,
-       CFG_VOL32 = 30 /* vol32.hip (cs_op_conv: force that kernel) */ };
+       CFG_VOL32 = 30 /* vol32.hip (cs_op_conv: force that kernel) */, CFG_WIDE = 31 /* conv_wide.hip (cs_op_conv: force that kernel) */ };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {
@@ -165,6 +165,9 @@ int launch_vol32_fused(const ResBlock3dCall& c, hipStream_t st);
 bool vol32_supported(const ConvParams& p);
 int vol32_stat_nblk(const ConvParams& p);        // partial-statistics blocks per sample when ConvParams::stat_out is set
 int launch_vol32(const ConvParams& p, hipStream_t st);
+// conv_wide.hip: persistent 3x3 kernel for the wide 2-D layers (256 x 256 workgroup tiles, 8 x 8 fragments per wave, one workgroup per CU)
+bool conv_wide_supported(const ConvParams& p, int mode);
+int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st);
 const half_t* cs_zero_page();   // per-process device buffer of zeros (lazily allocated on the current device)
 
 int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);

@@ -192,8 +192,8 @@ _Pragma("unroll") \
 #define EP_STAT_FLUSH(sg) \
     if (EP_STAT) { \
         const int ep_tiles = p.nTW * p.nTH * p.nTD; \
-        const int ep_nblk = ep_tiles * (BM / (EP_SG * 16)); \
-        const int ep_blk = (tile_lin % ep_tiles) * (BM / (EP_SG * 16)) + ep_wpx * (EP_WPX / EP_SG) + (sg); \
+        const int ep_nblk = EP_NBLK_V; \
+        const int ep_blk = EP_BLK_V(sg); \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
             const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
@@ -211,6 +211,17 @@ _Pragma("unroll") \
         } \
     }
 
+#ifndef EP_GSEL_V
+#define EP_GSEL_V 0       /* a kernel may fix the position blocks fetched per round itself (conv_wide.hip: a constexpr in its scope) */
+#endif
+#ifndef EP_BLK_V          /* partial-statistics block of (this wave, segment sg): kernels whose tile is not the one the block order was defined on override it */
+#define EP_BLK_V(sg) ((tile_lin % ep_tiles) * (BM / (EP_SG * 16)) + ep_wpx * (EP_WPX / EP_SG) + (sg))
+#define EP_NBLK_V (ep_tiles * (BM / (EP_SG * 16)))
+#endif
+#ifndef EP_SLICE_FENCE    /* executed after every position block of the epilogue (conv_wide.hip: a scheduling fence, so that the 256 accumulators \
+                             of its waves are read block by block instead of all at once) */
+#define EP_SLICE_FENCE
+#endif
 #ifndef EP_FG
 #define EP_FG 8           /* position blocks fetched per round in the fast paths of the 128x256 kernels (the general path: 2 / 1) */
 #endif
@@ -269,7 +280,7 @@ _Pragma("unroll") \
     constexpr bool EP_PF = (WCH != 5); \
     /* position blocks fetched per round: the whole tile where the register budget allows (no scratch, same occupancy step - \
        checked with tools/kernel_resources.py), else groups of 4 (128x128 tiles held to 168 registers), 2 (128x256 non-blend) or 1 (128x256 with 32 statistics accumulators) */ \
-    constexpr int EP_G = !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? (EPFAST ? (EP_STAT ? EP_FG_STAT : ((EPF & 3) == 2 ? EP_FG_F32 : EP_FG)) : (EP_STAT ? 1 : 2)) : 4))); \
+    constexpr int EP_G = (EP_GSEL_V) > 0 ? (EP_GSEL_V) : !EP_PF ? 1 : (EP_WPX < 8 ? EP_WPX : (MODE == MODE_TBLEND ? 8 : (WCH == 4 ? (EPFAST ? (EP_STAT ? EP_FG_STAT : ((EPF & 3) == 2 ? EP_FG_F32 : EP_FG)) : (EP_STAT ? 1 : 2)) : 4))); \
     constexpr int EP_NCI = EP_PF ? (WCH + CSTEP - 1) / CSTEP : 1; \
     const bool ep_fetch = EP_PF && ep_has_res; \
     /* channel pairs (EP_PAIR): fp16 tensors whose pointer and strides keep 8 channels 16-byte aligned get one access per pair */ \
@@ -440,6 +451,7 @@ _Pragma("unroll") \
                 } \
             } \
         } \
+        EP_SLICE_FENCE \
     } \
     } \
     EP_STAT_FLUSH((EP_WPX - 1) / EP_SG)

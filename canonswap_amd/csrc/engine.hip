@@ -336,6 +336,17 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         return amax_after(e, c, st);
     }
     if (c.p.xf_kind) { cs_set_error("%s: transform staging needs the vol32 kernel", c.name); return -1; }
+    // the wide 2-D 3x3 convs on the persistent kernel (conv_wide.hip: 256 x 256 workgroup tiles, 8 x 8 fragments per wave, one workgroup per
+    // CU) once every workgroup of its grid gets two items or more; the same bits as conv_halo (CANONSWAP_WIDE=0: A/B knob)
+    static const int wide_on = [] { const char* s = getenv("CANONSWAP_WIDE"); return s ? atoi(s) : 1; }();
+    if (wide_on && !e->latency_mode && c.hcfg < 0) {
+        static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
+        c.p.ep_general = epg;
+        if (conv_wide_supported(c.p, c.mode) && (long)c.p.N * (c.p.H / 16) * (c.p.W / 16) * (c.p.Cout_pad / 256) >= 512) {
+            TRY(e->run(0, st, [&] { return launch_conv_wide(c.p, c.mode, st); }, c.name, fl));
+            return amax_after(e, c, st);
+        }
+    }
     if (c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
@@ -1576,6 +1587,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     }
     c.mode = d->mode;
     if (d->cfg == CFG_VOL32) return launch_vol32(p, (hipStream_t)stream);
+    if (d->cfg == CFG_WIDE) return launch_conv_wide(p, c.mode, (hipStream_t)stream);
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo
         const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;
