@@ -29,16 +29,19 @@
 #define EP_GSEL_V EP_GSEL_K      /* position blocks whose residual / mask the epilogue fetches per round: set per instantiation below */
 #define EP_SLICE_FENCE __builtin_amdgcn_sched_barrier(0);
 #include "conv_epilogue.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int W_SLP = 10, W_VS = W_SLP * 16;          // slots per voxel (8 data + 2 pad), bytes per voxel
 constexpr int W_HW = 18, W_HV = W_HW * W_HW;          // halo of a 16 x 16 tile
-constexpr int W_BUF = W_HV * W_VS;                    // 51 840 bytes per buffer
+constexpr int W_BUF = W_HV * W_VS;                    // 51 840 bytes of a chunk's image
 constexpr int W_NPIECE = W_HV * W_SLP;                // 3240 16-byte pieces per chunk
 constexpr int W_HI = (W_NPIECE + 255) / 256;          // 13 pieces per thread
+constexpr int W_BSTRIDE = W_HI * 4096;                // LDS bytes between the two buffers: the last piece's lanes beyond the image land in the gap
 constexpr int W_PFS = 3;                              // weight ring depth in K-steps (a K-step is 64 MFMAs ~ 1 000 cycles)
 constexpr int W_NT = 9, W_NS = 18;                    // taps, K-steps per 64-channel chunk
+constexpr int W_ST0 = 1;                              // K-steps W_ST0 .. W_ST0 + 12 of a chunk each issue one DMA piece of the next chunk
 
 typedef unsigned int u4w_t __attribute__((ext_vector_type(4)));
 
@@ -49,6 +52,16 @@ struct WideAcc3 { const f4_t& v; __device__ __forceinline__ float operator[](int
 struct WideAcc2 { const f4_t (&row)[8]; __device__ __forceinline__ WideAcc3 operator[](int pi) const { return WideAcc3{row[pi]}; } };
 struct WideAcc1 { const f4_t (&a)[8][8]; __device__ __forceinline__ WideAcc2 operator[](int ci) const { return WideAcc2{a[ci]}; } };
 
+// -DW_TL (tools/wide_probe.py, instrumented A/B build only): every wave accumulates s_memtime cycles per phase of its life
+#ifdef W_TL
+unsigned long long* g_wide_tl = nullptr;
+long g_wide_tl_cap = 0;
+#define WTL(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl_acc[i] += t_ - tl_last; tl_last = t_; \
+                    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WTL(i) do { } while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wide_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // schedule of the persistent grid (set by the launcher)
@@ -58,6 +71,10 @@ struct WideSched {
     int ncb;           // 256-channel blocks of the layer (1, 2, 4)
     int tg;            // tile groups per XCD = (G / 8) / ncb
     int t8;            // tiles per XCD (contiguous range)
+    int in_bytes;      // bytes the input tensor spans (< 2^31): the DMA's buffer range
+#ifdef W_TL
+    unsigned long long* tl; long tl_cap;     // 12 x u64 per wave: cycles in [startup, ring prime, vm wait, barrier, stage, main loop, next-item stage, epilogue], items, chunks, hw id, end time
+#endif
 };
 
 // EPC: the tensor combination of the launch as a compile-time constant (EP_CODE of conv_epilogue.h): straight-line epilogue, counted waits
@@ -73,6 +90,9 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
     const int wp = wave & 1, wch = wave >> 1;        // position half (rows wp * 8 ..), channel half (packed rows wch * 128 ..)
     const int l15 = lane & 15, l4 = lane >> 4;
     const int l15p = l15;
+#ifdef W_TL
+    unsigned long long tl_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_last = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- this workgroup's item list: channel block cb (fixed), tiles xcd * t8 + tgi + tg * j
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
@@ -86,20 +106,17 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
 
     const int isN = (int)p.in_sN, isH = (int)p.in_sH, isW = (int)p.in_sW;
     // ---- halo staging: piece q = tid + 256 * j of a chunk <-> (voxel q / 10, slot q % 10); global -> LDS directly, pad slots are not fetched
-    int poff[W_HI];
-    unsigned pmask = 0;                              // bit j: piece j lies inside the image (else it reads the zero page)
-    unsigned pdata = 0;                              // bit j: piece j is a data slot of an existing halo voxel (else not issued at all)
-#pragma unroll
-    for (int j = 0; j < W_HI; ++j) {
-        const int q = tid + 256 * j;
-        if (q < W_NPIECE && (q % W_SLP) < 8) pdata |= 1u << j;
-    }
-    auto setup_item = [&](int tile) {
-        int t = tile;
+    // Buffer-addressed DMA (buffer_load_dwordx4 ... lds): a lane whose byte offset lies outside the buffer gets zeros, so pad slots, voxels
+    // outside the image and the lanes of the last piece beyond the image carry a sentinel offset - no zero page, no per-piece address select
+    // (two instructions per piece in the K loop: the LDS base into M0 and the load; the chunk's channel offset is the scalar offset).
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, s.in_bytes, 0x00020000);
+    constexpr unsigned W_OOB = 0x80000000u;          // launcher: the input spans less than 2^31 bytes
+    unsigned poff[W_HI];                             // byte offset of piece j's 16 bytes at channel 0 of the chunk
+    auto setup_item = [&](int tile) {                // tile < 0: nothing to stage (every piece is out of range)
+        int t = tile < 0 ? 0 : tile;
         const int tw = t % s.nTW; t /= s.nTW;
         const int th = t % s.nTH; t /= s.nTH;
         const int base = t * isN;
-        pmask = 0;
         // (the thread index goes through an opaque move: otherwise the item-invariant part of this addressing - 3 values per piece - is hoisted
         // out of the item loop and held in registers across the main loop, and the kernel spills)
         int tid_o = tid;
@@ -110,21 +127,15 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
             const int hv = q / W_SLP, sl = q % W_SLP;
             const int hh = hv / W_HW, hw = hv % W_HW;
             const int ih = th * 16 + hh - 1, iw = tw * 16 + hw - 1;
-            const bool inb = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            poff[j] = inb ? base + __mul24(ih, isH) + __mul24(iw, isW) + sl * 8 : 0;
-            pmask |= inb ? (1u << j) : 0u;
+            const bool inb = tile >= 0 && q < W_NPIECE && sl < 8 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            poff[j] = inb ? (unsigned)(base + __mul24(ih, isH) + __mul24(iw, isW) + sl * 8) * 2u : W_OOB;
         }
     };
-    auto stage = [&](int buf, int c0) {              // asynchronous (vmcnt): awaited by the counted wait + barrier at the chunk's head
-#pragma unroll
-        for (int j = 0; j < W_HI; ++j) {
-            if ((pdata >> j) & 1u) {
-                const half_t* src = ((pmask >> j) & 1u) ? p.in + poff[j] + c0 : p.zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(smem + (size_t)buf * W_BUF + (size_t)(256 * j + wave * 64) * 16),
-                                                 16, 0, 0);
-            }
-        }
+    // piece j of a chunk, asynchronous (vmcnt): awaited by the counted wait + barrier at the chunk's head.  Every lane takes part (no exec
+    // mask, no branch: the K-steps that carry a piece stay one scheduling region).
+    auto stage_piece = [&](int buf, int c0, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(smem + (size_t)buf * W_BSTRIDE + (size_t)(256 * j + wave * 64) * 16),
+                                                 16, (int)poff[j], c0 * 2, 0, 0);
     };
 
     // ---- operand addressing.  Activation fragment pi of this wave = row wp * 8 + pi of the tile, 16 positions along w (l15), k slot l4;
@@ -139,9 +150,11 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
     int tile = tile_of(0);
     if (tile < 0) return;
     setup_item(tile);
-    stage(0, 0);
+#pragma unroll
+    for (int j = 0; j < W_HI; ++j) stage_piece(0, 0, j);
     int gbuf = 0;                                    // buffer of the chunk about to be computed
 
+    WTL(0);
     while (tile >= 0) {
         // coordinates of the item being computed (the staging registers move on to the next item during its last chunk)
         const int tile_lin = tile;
@@ -159,26 +172,56 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
 #pragma unroll
             for (int pi = 0; pi < WPX; ++pi) acc[ci][pi] = (f4_t){0.f, 0.f, 0.f, 0.f};
 
+        // ---- weight ring: W_PFS K-steps x 8 fragments, streamed global -> VGPR with loads the compiler does not track (inline asm) and
+        // waited for with counted s_waitcnt.  With compiler-tracked loads every wait for a fragment degenerates to vmcnt(0) while an LDS DMA
+        // of the halo is in flight (hipcc treats the two kinds of vmcnt events as returning out of order), i.e. no halo piece could be
+        // staged under the MFMAs at all; it also drains vmcnt at the chunk loop's back-edge.  The waits name the slot's registers as
+        // read-write operands, so no consumer can be scheduled above them; tools/../_lib.isa_check_wide verifies in the disassembly that every
+        // MFMA's weight operand was written by a ring load (never a copy of one).
         u4w_t wr[W_PFS][WCH];
-        auto wload_at = [&](u4w_t (&dst)[WCH], int cc, int st) {          // st: compile-time after unrolling
-            const int ccl = cc < nck ? cc : nck - 1;                      // behind the last chunk the carried fetches repeat and are dropped
-            const half_t* src = wlane + (long)((ccl * 2 + st % 2) * W_NT + st / 2) * wstep;
-#pragma unroll
-            for (int ci = 0; ci < WCH; ++ci) dst[ci] = *(const u4w_t*)(src + ep_frag_row(EP_PAIR, ci) * 32);
+        auto wsrc_of = [&](int cc, int st) -> const half_t* {            // st: compile-time after unrolling (may run into the next chunk)
+            const int c2 = cc + st / W_NS, s2 = st % W_NS;
+            const int ccl = c2 < nck ? c2 : nck - 1;                      // behind the last chunk the carried fetches repeat and are dropped
+            return wlane + (long)((ccl * 2 + s2 % 2) * W_NT + s2 / 2) * wstep;
         };
+        auto wload1 = [&](u4w_t& dst, const half_t* src, int ci) {        // ci: compile-time after unrolling
+            // two base pointers: the fragments' row offsets (ep_frag_row) reach beyond the 12-bit instruction offset
+            const half_t* b = src + ep_frag_row(EP_PAIR, ci & 4) * 32;
+            const int off = (ep_frag_row(EP_PAIR, ci) - ep_frag_row(EP_PAIR, ci & 4)) * 64;
+            if (off == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(b));
+            else if (off == 256) asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(dst) : "v"(b));
+            else if (off == 1024) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(dst) : "v"(b));
+            else if (off == 1280) asm volatile("global_load_dwordx4 %0, %1, off offset:1280" : "=v"(dst) : "v"(b));
+            else if (off == 2048) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(dst) : "v"(b));
+            else if (off == 2304) asm volatile("global_load_dwordx4 %0, %1, off offset:2304" : "=v"(dst) : "v"(b));
+            else __builtin_trap();
+        };
+#define WIDE_RING_WAIT(N, S) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(wr[S][0]), "+v"(wr[S][1]), "+v"(wr[S][2]), "+v"(wr[S][3]), \
+                                                                     "+v"(wr[S][4]), "+v"(wr[S][5]), "+v"(wr[S][6]), "+v"(wr[S][7]))
+        static_assert(W_PFS == 3 && W_NS % W_PFS == 0, "the counted waits below are written for a three-slot ring");
 #pragma unroll
-        for (int st = 0; st < W_PFS; ++st) wload_at(wr[st], 0, st);
+        for (int st = 0; st < W_PFS; ++st)
+#pragma unroll
+            for (int ci = 0; ci < WCH; ++ci) wload1(wr[st][ci], wsrc_of(0, st), ci);
+        WTL(1);
 
         for (int cc = 0; cc < nck; ++cc) {
             // ---- head of a chunk: its halo (staged one chunk ago by every wave) has landed: this wave's pieces by the counted wait - the
             // ring fetches (and, at an item's first chunk, the previous epilogue's stores) are younger and stay in flight -, everyone's by
             // the barrier, which also says that everyone has left the other buffer.  Then the next chunk (or the next item's first one,
             // whose addressing is computed here, under the MFMAs that follow) goes into that buffer.
-            wide_wait_vm<W_PFS * WCH>();
+            wide_wait_vm<(W_PFS - 1) * WCH>();
+            WTL(2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (cc + 1 < nck) stage(gbuf ^ 1, (cc + 1) * 64);
-            const unsigned char* hb = smem + (size_t)gbuf * W_BUF + abase0;
+            WTL(3);
+            // the next chunk - or the next item's first one, whose addressing replaces this item's here - is staged piece by piece under the
+            // K-steps below
+            int c0n = (cc + 1) * 64;
+            if (cc + 1 == nck) { setup_item(next_tile); c0n = 0; }
+            const int nbuf = gbuf ^ 1;
+            WTL(4);
+            const unsigned char* hb = smem + (size_t)gbuf * W_BSTRIDE + abase0;
             gbuf ^= 1;
 
             // ---- 18 K-steps, fully unrolled.  Position fragments in two halves: while the MFMAs of one half run, the LDS reads of the
@@ -191,45 +234,67 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
             h8_t afA[HA], afB[WPX - HA];
 #pragma unroll
             for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + pi * (W_HW * W_VS) + toff_of(0));
+            // Issue order of a step, pinned by scheduling fences (the asm loads are opaque to the scheduler's instruction classes):
+            //   wait for the step's ring slot | 16 MFMA pairs on position fragments 0-3, with pair k: LDS read of fragment 2 + k (2 <= k < 6) or
+            //   reload of fragment k - 6 of the slot the previous step used (6 <= k < 14) | one DMA piece of the next chunk | 16 MFMA pairs on
+            //   fragments 4-7, with pairs 2-5 the LDS reads of the next step's fragments 0-3.
+            // (Pairs 0 and 1 of a half touch all four fragments the previous half read and carry no LDS read: hipcc waits for LDS data with
+            // lgkmcnt(0) while it believes an LDS DMA is pending - it never sees the counted vmcnt waits -, so a read issued before those first
+            // uses would be waited for right away: 100 cycles of idle matrix pipe per half.)
+            // VMEM instructions younger than the loads of step st's slot when the step starts: the 8 reloads of step st - 1 plus the DMA pieces
+            // of steps st - 2 and st - 1 (step 0: the 16 loads of the two other slots; they were issued behind the previous chunk's step 16).
 #pragma unroll
             for (int st = 0; st < W_NS; ++st) {
                 const int toff = toff_of(st);
-#pragma unroll
-                for (int pi = HA; pi < WPX; ++pi) afB[pi - HA] = *(const h8_t*)(hb + pi * (W_HW * W_VS) + toff);
-                if (st >= 1) {
-                    if (st - 1 + W_PFS < W_NS) wload_at(wr[(st - 1) % W_PFS], cc, st - 1 + W_PFS);
-                    else wload_at(wr[(st - 1) % W_PFS], cc + 1, (st - 1 + W_PFS) - W_NS);
+                constexpr int S0 = 0;
+                (void)S0;
+                {
+                    const bool d2 = st - 2 >= W_ST0 && st - 2 < W_ST0 + W_HI, d1 = st - 1 >= W_ST0 && st - 1 < W_ST0 + W_HI;
+                    const int nyoung = st == 0 ? 16 : 8 + (d2 ? 1 : 0) + (d1 ? 1 : 0);
+                    const int sl = st % W_PFS;
+                    // (the count must be an instruction immediate: one asm per (count, slot))
+                    if (nyoung == 16) { if (sl == 0) WIDE_RING_WAIT(16, 0); else if (sl == 1) WIDE_RING_WAIT(16, 1); else WIDE_RING_WAIT(16, 2); }
+                    else if (nyoung == 8) { if (sl == 0) WIDE_RING_WAIT(8, 0); else if (sl == 1) WIDE_RING_WAIT(8, 1); else WIDE_RING_WAIT(8, 2); }
+                    else if (nyoung == 9) { if (sl == 0) WIDE_RING_WAIT(9, 0); else if (sl == 1) WIDE_RING_WAIT(9, 1); else WIDE_RING_WAIT(9, 2); }
+                    else { if (sl == 0) WIDE_RING_WAIT(10, 0); else if (sl == 1) WIDE_RING_WAIT(10, 1); else WIDE_RING_WAIT(10, 2); }
                 }
-#pragma unroll
-                for (int ci = 0; ci < WCH; ++ci)
-#pragma unroll
-                    for (int pi = 0; pi < HA; ++pi)
-                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % W_PFS][ci]), afA[pi], acc[ci][pi], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < WPX - HA; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-#pragma unroll
-                for (int i = 0; i < WCH; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
                 __builtin_amdgcn_sched_barrier(0);
-                if (st + 1 < W_NS) {
+                const half_t* rsrc = wsrc_of(cc, st - 1 + W_PFS);       // step st reloads the slot of step st - 1
 #pragma unroll
-                    for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + pi * (W_HW * W_VS) + toff_of(st + 1));
+                for (int k = 0; k < 16; ++k) {
+                    const int ci = k >> 1, p0 = (k & 1) * 2;
+                    acc[ci][p0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % W_PFS][ci]), afA[p0], acc[ci][p0], 0, 0, 0);
+                    acc[ci][p0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % W_PFS][ci]), afA[p0 + 1], acc[ci][p0 + 1], 0, 0, 0);
+                    if (k >= 2 && k < 6) afB[k - 2] = *(const h8_t*)(hb + (HA + k - 2) * (W_HW * W_VS) + toff);
+                    else if (k >= 6 && k < 14 && st >= 1) wload1(wr[(st - 1) % W_PFS][k - 6], rsrc, k - 6);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                // one DMA piece of the next chunk per K-step (a burst of 13 at the chunk's head idled the matrix pipe for 1 200 cycles of a
+                // 20 000-cycle chunk, and for 4 000 at an item's end; profiles/r04_b_wide_probe.txt)
+                if (st >= W_ST0 && st < W_ST0 + W_HI) { stage_piece(nbuf, c0n, st - W_ST0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-                for (int ci = 0; ci < WCH; ++ci)
-#pragma unroll
-                    for (int pi = HA; pi < WPX; ++pi)
-                        acc[ci][pi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % W_PFS][ci]), afB[pi - HA], acc[ci][pi], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < HA; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < 16; ++k) {
+                    const int ci = k >> 1, p0 = (k & 1) * 2;
+                    acc[ci][HA + p0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % W_PFS][ci]), afB[p0], acc[ci][HA + p0], 0, 0, 0);
+                    acc[ci][HA + p0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % W_PFS][ci]), afB[p0 + 1], acc[ci][HA + p0 + 1], 0, 0, 0);
+                    if (k >= 2 && k < 6 && st + 1 < W_NS) afA[k - 2] = *(const h8_t*)(hb + (k - 2) * (W_HW * W_VS) + toff_of(st + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            // W_NS % W_PFS == 0: step W_NS - 1 used slot (W_NS - 1) % W_PFS, which serves step W_PFS - 1 of the next chunk
-            wload_at(wr[(W_NS - 1) % W_PFS], cc + 1, W_PFS - 1);
+            {   // step W_NS - 1 used slot (W_NS - 1) % W_PFS, which serves step W_PFS - 1 of the next chunk
+                const half_t* rsrc = wsrc_of(cc, W_NS - 1 + W_PFS);
+#pragma unroll
+                for (int ci = 0; ci < WCH; ++ci) wload1(wr[(W_NS - 1) % W_PFS][ci], rsrc, ci);
+            }
+            WTL(5);
+#ifdef W_TL
+            tl_acc[9] += 1;
+#endif
         }
 
-        // ---- the next item's first chunk goes into the buffer the last chunk did not read (everyone left it before that chunk's barrier): it
-        // lands while the epilogue runs
-        if (next_tile >= 0) { setup_item(next_tile); stage(gbuf, 0); }
+        wide_wait_vm<0>();      // the ring's last (dropped) fetches are loads the compiler does not know of: they must have landed before it reuses their registers
+        __builtin_amdgcn_sched_barrier(0);
+        WTL(6);
         // ---- epilogue (conv_epilogue.h): the tensor combination is a compile-time constant.  Stores are not waited for here.
         {
             constexpr bool EP_HEAVY = false, EP_EARLY = false;
@@ -242,16 +307,33 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
             const WideAcc1 ep_acc{acc};
             CONV_EPILOGUE_IMPL(EPC);
         }
+        WTL(7);
+#ifdef W_TL
+        tl_acc[8] += 1;
+#endif
         tile = next_tile;
         ++j_item;
     }
+#ifdef W_TL
+    if (s.tl && lane == 0) {
+        const long wi = (long)blockIdx.x * 4 + wave;
+        if (wi < s.tl_cap) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned long long* o = s.tl + wi * 12;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) o[i] = tl_acc[i];
+            o[10] = hwid; o[11] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 template <int MODE, int EPC>
 int launch_wide_inst(const ConvParams& p, const WideSched& s, int grid, hipStream_t st)
 {
     auto k = conv_wide_kernel<MODE, EPC>;
-    const size_t lds = 2 * (size_t)W_BUF;
+    const size_t lds = 2 * (size_t)W_BSTRIDE;
     static bool attr_done = false;                   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -295,17 +377,21 @@ int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st)
 {
     if (!conv_wide_supported(p, mode)) { cs_set_error("conv_wide: this launch is not one of the kernel's shapes / tensor combinations"); return -1; }
     {
-        const long in_span = (long)(p.N - 1) * p.in_sN + (long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW + p.Cin;
-        if (in_span >= (1L << 31) || p.in_sH >= (1L << 23) || p.in_sW >= (1L << 23)) { cs_set_error("conv_wide: input too large for 32-bit offsets / 24-bit axis products"); return -1; }
         if (ep_check_extents(p, "conv_wide")) return -1;
     }
+    const long in_span = (long)(p.N - 1) * p.in_sN + (long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW + p.Cin;
+    if (in_span >= (1L << 30) || p.in_sH >= (1L << 23) || p.in_sW >= (1L << 23)) { cs_set_error("conv_wide: input too large for 31-bit byte offsets / 24-bit axis products"); return -1; }
     WideSched s;
+    s.in_bytes = (int)(in_span * 2);
     s.nTW = p.W / 16; s.nTH = p.H / 16;
     s.ntiles = p.N * s.nTW * s.nTH;
     s.ncb = p.Cout_pad / 256;
     const int G = 256;                                // one workgroup per CU; 32 per XCD
     s.tg = (G / 8) / s.ncb;
     s.t8 = (s.ntiles + 7) / 8;
+#ifdef W_TL
+    s.tl = g_wide_tl; s.tl_cap = g_wide_tl_cap;
+#endif
     ConvParams kp = p;
     const int code = wide_ep_code(p);
     if (mode == MODE_TBLEND) {
@@ -315,3 +401,8 @@ int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st)
     cs_set_error("conv_wide: no instantiation for mode %d / epilogue code %d", mode, code);
     return -1;
 }
+
+#ifdef W_TL
+// instrumented builds only: device buffer of cap x 12 u64 that every following conv_wide launch fills (nullptr: off)
+extern "C" void cs_debug_set_wide_tl(void* buf, long cap) { g_wide_tl = (unsigned long long*)buf; g_wide_tl_cap = cap; }
+#endif

@@ -1,0 +1,81 @@
+"""conv_wide alone at the engine's T shapes (B x 64 x 64 x 512 -> 2 x 512): microseconds per launch by HIP events next to conv_halo's
+128 x 256 tile and, with the instrumented build (python tools/build_variant.py wtl -DW_TL; CANONSWAP_LIB=ab/wtl.so), where a wave's cycles go.
+
+    python tools/wide_probe.py [--batch 64] [--reps 10]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hip_ops as ops  # noqa: E402
+from canonswap_amd import _lib, pack  # noqa: E402
+
+DEV = "cuda:0"
+PH = ["startup", "ring prime", "vm wait", "barrier", "stage", "main loop", "next-item stage", "epilogue"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--cfgs", default="17,31")
+    a = ap.parse_args()
+    B, Cc = a.batch, 512
+    r = np.random.Generator(np.random.PCG64(3))
+    lib = _lib.load()
+    tl = None
+    if hasattr(lib, "cs_debug_set_wide_tl"):
+        cap = 1024
+        tl = torch.zeros(cap * 12, dtype=torch.int64, device=DEV)
+        lib.cs_debug_set_wide_tl.argtypes = [C.c_void_p, C.c_long]
+        lib.cs_debug_set_wide_tl(C.c_void_p(tl.data_ptr()), cap)
+    x = torch.relu(torch.randn(B, 1, 64, 64, Cc, device=DEV)).half()
+    sc = 1.0 / np.sqrt(9 * Cc)
+    w = (sc * r.standard_normal((2 * Cc, Cc, 3, 3))).astype(np.float32)
+    wp = torch.from_numpy(pack.pack_conv(w, 2 * Cc)).to(DEV)
+    bias = torch.randn(Cc, device=DEV) * 0.1
+    m4 = torch.rand(B, 64, 64, 4, device=DEV)
+    res = torch.randn(B, 1, 64, 64, Cc, device=DEV)
+    o16 = torch.empty(B, 1, 64, 64, Cc, dtype=torch.float16, device=DEV)
+    o32 = torch.empty(B, 1, 64, 64, Cc, dtype=torch.float32, device=DEV)
+    s2 = torch.rand(Cc, device=DEV) + 0.5
+    gfl = 2 * 9 * Cc * 2 * Cc * B * 4096 / 1e9
+    for cfg in [int(c) for c in a.cfgs.split(",")]:
+        cases = {
+            "conv1 (blend, relu, fp16 out)": lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, act0="relu", out0=o16, mode=1, cfg=cfg),
+            "conv2 (blend, fp32 res, fp32 + fp16 out)": lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, res=res, out0=o32,
+                                                                          s2=s2, t2=bias, act1="relu", out1=o16, mode=1, cfg=cfg),
+        }
+        for name, fn in cases.items():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / a.reps
+            print(f"cfg {cfg} {name:42s} {us:8.1f} us/launch  {gfl / us * 1e-3:7.1f} TFLOP/s ({gfl / us * 1e-3 / 2500:.3f} of peak)")
+            if tl is not None and cfg == 31:
+                tl.zero_()
+                fn()
+                torch.cuda.synchronize()
+                t = tl.view(-1, 12).cpu().numpy()
+                t = t[t[:, 8] > 0]
+                life = t[:, :8].sum(axis=1)
+                print(f"   waves {len(t)}, items/wave {t[:, 8].mean():.1f}, chunks {t[:, 9].mean():.0f}, life {life.mean():.0f} cycles (min {life.min()}, max {life.max()})")
+                print("   " + "  ".join(f"{PH[i]} {t[:, i].mean():.0f} ({t[:, i].mean() / life.mean():.1%})" for i in range(8)))
+                print("   per chunk: " + "  ".join(f"{PH[i]} {t[:, i].mean() / t[:, 9].mean():.0f}" for i in (2, 3, 4, 5)) +
+                      "   per item: " + "  ".join(f"{PH[i]} {t[:, i].mean() / t[:, 8].mean():.0f}" for i in (1, 6, 7)))
+
+
+if __name__ == "__main__":
+    main()
