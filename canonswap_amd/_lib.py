@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
     "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged", "cs_op_resblock3d", "cs_op_t_mask",
 ]
+ABI_VERSION = 2          # CS_ABI_VERSION of include/canonswap_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -123,8 +124,8 @@ def isa_check(obj_dir: str | None = None) -> dict:
     obj_dir = obj_dir or OBJ_DIR
     objdump = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
     if not os.path.exists(objdump):
-        raise RuntimeError(f"isa_check: {objdump} not found")
-    seen = {}
+        raise FileNotFoundError(f"isa_check: {objdump} not found")      # build() reports the check as skipped; a failed check is a RuntimeError
+    seen = dict(_isa_check_wide(obj_dir, objdump))
     for g in range(HALO_NGROUPS):
         obj = os.path.join(obj_dir, f"conv_halo_g{g}.o")
         subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True)
@@ -169,6 +170,61 @@ def isa_check(obj_dir: str | None = None) -> dict:
     return seen
 
 
+def _isa_check_wide(obj_dir: str, objdump: str) -> dict:
+    """conv_wide.hip streams its weight ring with untracked inline-asm loads and waits with counted `s_waitcnt vmcnt(N)` that name the slot's
+    registers.  Check in the disassembly of every conv_wide kernel: each MFMA's weight operand (src0) is a VGPR quadruple whose last writer
+    is a `global_load_dwordx4` (never a copy of one: a copy made before the data landed would be stale) with a vmcnt wait between that load
+    and the MFMA; 18 K-steps x 64 MFMAs per kernel."""
+    import re
+    obj = os.path.join(obj_dir, "conv_wide.o")
+    subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True)
+    co = obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950"
+    try:
+        txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        for f in os.listdir(obj_dir):
+            if f.startswith("conv_wide.o.0."):
+                os.remove(os.path.join(obj_dir, f))
+    seen = {}
+    for m in re.finditer(r"^[0-9a-f]+ <(\S*conv_wide_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        writer, waited, nmfma = {}, {}, 0
+        for l in body:
+            t = l.split("//")[0].strip()
+            if not t:
+                continue
+            op = t.split()[0]
+            if op.startswith("s_waitcnt") and "vmcnt" in t:
+                for r in waited:
+                    waited[r] = True
+            if op.startswith("v_mfma"):
+                ops = re.findall(r"([av])\[(\d+):(\d+)\]", t)
+                if len(ops) < 4 or ops[1][0] != "v":
+                    raise RuntimeError(f"isa_check: {name}: MFMA with a weight operand outside the VGPRs: {t}")
+                nmfma += 1
+                for r in range(int(ops[1][1]), int(ops[1][2]) + 1):
+                    if not writer.get(r, "").startswith("global_load_dwordx4"):
+                        raise RuntimeError(f"isa_check: {name}: v{r}, a weight operand of `{t}`, was last written by `{writer.get(r)}` (a copy of a ring register?)")
+                    if not waited.get(r, False):
+                        raise RuntimeError(f"isa_check: {name}: no vmcnt wait between the ring load of v{r} and `{t}`")
+                continue
+            if op.startswith(("global_store", "buffer_store", "ds_write", "scratch_store", "s_", "buffer_load_dwordx4")) and "lds" in t + " lds" and not op.startswith("global_load"):
+                if not op.startswith(("v_", "ds_read", "global_load", "scratch_load")):
+                    continue
+            mm = re.match(r"\S+\s+(v\[(\d+):(\d+)\]|v(\d+))", t)
+            if mm and not op.startswith(("global_store", "buffer_store", "ds_write", "scratch_store")) and not (op.startswith("buffer_load") and t.endswith("lds")):
+                rng = range(int(mm.group(2)), int(mm.group(3)) + 1) if mm.group(2) else [int(mm.group(4))]
+                for r in rng:
+                    writer[r] = op
+                    waited[r] = False
+        if nmfma != 18 * 64:
+            raise RuntimeError(f"isa_check: {name}: {nmfma} MFMAs in the kernel, expected 18 K-steps x 64")
+        seen[name] = nmfma
+    if not seen:
+        raise RuntimeError("isa_check: no conv_wide kernel found in conv_wide.o (name mangling changed?)")
+    return seen
+
+
 class ConvDesc(C.Structure):
     """Mirror of cs_conv_desc (include/canonswap_hip.h)."""
     _fields_ = [
@@ -208,6 +264,9 @@ def load():
             f"{LIB_PATH} is missing: the HIP engine has not been built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(needs hipcc); canonswap_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    if lib.cs_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} speaks C-ABI version {lib.cs_abi_version()}, this package binds version {ABI_VERSION} "
+                           "(include/canonswap_hip.h: CS_ABI_VERSION): rebuild with __graft_entry__.build()")
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     lib.cs_last_error.restype = C.c_char_p
     lib.cs_create.argtypes = [ci, ci, C.POINTER(vp)]

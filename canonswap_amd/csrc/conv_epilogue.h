@@ -187,6 +187,25 @@ _Pragma("unroll") \
         } \
     }
 
+// Sum over the 16 lanes of a row (the 16 positions of an MFMA block), valid in the row's lane 0, with the bits of the xor butterfly
+// a += shfl_xor(a, 1), 2, 4, 8 there: lane 0 of that butterfly only ever combines values from lanes i and i + o (i a multiple of 2 o), which
+// is what a row shift by o delivers.  As DPP operands of the adds these are 4 VALU instructions; the shuffles were 4 ds_bpermute round
+// trips per value (the statistics epilogue of a 128 x 128 wave tile: 27 000 of 34 000 cycles, profiles/r04_d_wide_probe.txt).
+__device__ __forceinline__ float ep_row_sum16(float a)
+{
+#ifdef EP_HOST_EMULATION
+    for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o, 64);
+    return a;
+#else
+    // row_shl:n (dpp_ctrl 0x100 + n): lane i reads lane i + n of its row of 16; lanes that would read beyond the row get 0 (bound_ctrl)
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x101, 0xf, 0xf, true));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x102, 0xf, 0xf, true));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x104, 0xf, 0xf, true));
+    a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x108, 0xf, 0xf, true));
+    return a;
+#endif
+}
+
 // partial statistics of segment sg (EP_SG position blocks of this wave): fixed-order butterfly over the 16 position lanes, one
 // partial per (tile, segment, channel); executed by all lanes
 #define EP_STAT_FLUSH(sg) \
@@ -197,16 +216,18 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int ci = 0; ci < WCH; ci += CSTEP) { \
             const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
+            float ep_pa[4], ep_pb[4]; \
 _Pragma("unroll") \
             for (int r = 0; r < 4; ++r) { \
-                float a = ep_sum[EP_STAT ? ci : 0][r], b = ep_sq[EP_STAT ? ci : 0][r]; \
+                ep_pa[r] = ep_row_sum16(ep_sum[EP_STAT ? ci : 0][r]); ep_pb[r] = ep_row_sum16(ep_sq[EP_STAT ? ci : 0][r]); \
                 ep_sum[EP_STAT ? ci : 0][r] = 0.f; ep_sq[EP_STAT ? ci : 0][r] = 0.f; \
-_Pragma("unroll") \
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); } \
-                if (l15 == 0 && cb < p.Cout) { \
-                    float* dst = p.stat_out + (((long)tn * ep_nblk + ep_blk) * p.Cout + cb + r) * 2; \
-                    dst[0] = a; dst[1] = b; \
-                } \
+            } \
+            /* the (sum, sum of squares) pairs of the lane's 4 channels are 32 contiguous bytes: two 16-byte stores instead of eight 4-byte ones \
+               (p.Cout is a multiple of 4 and cb of 4: all four channels exist or none; the launchers refuse anything else) */ \
+            if (l15 == 0 && cb < p.Cout) { \
+                float4* dst = (float4*)(p.stat_out + (((long)tn * ep_nblk + ep_blk) * p.Cout + cb) * 2); \
+                dst[0] = make_float4(ep_pa[0], ep_pb[0], ep_pa[1], ep_pb[1]); \
+                dst[1] = make_float4(ep_pa[2], ep_pb[2], ep_pa[3], ep_pb[3]); \
             } \
         } \
     }
@@ -231,6 +252,36 @@ _Pragma("unroll") \
 #ifndef EP_FG_STAT
 #define EP_FG_STAT 4
 #endif
+#ifndef EP_PIPE_V
+#define EP_PIPE_V 0
+#endif
+/* one fetch round of the epilogue: residual / modulated tensor / per-position scale of the position blocks PG0 .. PG0 + EP_G - 1 -> register set BI */
+#define EP_FETCH_ROUND(PG0, BI) \
+    if (EP_PF && !EP_EARLY && (ep_fetch || ep_has_ps)) { \
+_Pragma("unroll") \
+        for (int g = 0; g < EP_G; ++g) { \
+            int bw, bh, bd, bn; \
+            { int t = (ep_wpx * EP_WPX + (PG0) + g) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
+            if (!EPFAST && ep_nb + ep_ln + bn >= p.N) continue; \
+            if (ep_has_ps) ep_ps2[BI][g] = p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
+            if (ep_fetch) { \
+                const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + \
+                                                            (bw >> ep_rs) * (int)p.res.sW); \
+_Pragma("unroll") \
+                for (int ci = 0; ci < WCH; ci += CSTEP) { \
+                    const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
+                    if (!EPALL && cb >= p.Cout) continue; \
+                    if (ep_res32) ep_raw2[BI][g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + (xb + (unsigned)cb)); \
+                    else if (ep_mr && ep_second(EP_PAIR, ci)) { /* came with the pair's first half */ } \
+                    else if (ep_mr && (EPALL || cb + 4 < p.Cout)) ep_raw2[BI][g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
+                    else { \
+                        const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
+                        ep_raw2[BI][g][(EP_PF ? ci / CSTEP : 0)][0] = q2[0]; ep_raw2[BI][g][(EP_PF ? ci / CSTEP : 0)][1] = q2[1]; \
+                    } \
+                } \
+            } \
+        } \
+    }
 #define CONV_EPILOGUE_IMPL(EPCODE) \
     constexpr int EPF = (EPCODE); \
     constexpr bool EPFAST = EPF >= 0; \
@@ -310,34 +361,19 @@ _Pragma("unroll") \
     const unsigned ep_lane_ps = (unsigned)(((((ep_nb + ep_ln) * p.D + ep_d0 + ep_ld) * p.H + ep_h0 + ep_lh) * p.W + ep_w0 + ep_lw) * p.ps_stride); \
     /* pixel shuffle: out[n][c][2h + i][2w + j], H2 = 2H, W2 = 2W */ \
     const unsigned ep_lane_px = (unsigned)((((ep_nb + ep_ln) * 3) * 2 * p.H + 2 * (ep_h0 + ep_lh)) * 2 * p.W + 2 * (ep_w0 + ep_lw)); \
+    /* EP_PIPE_V (a kernel's choice; 0 elsewhere): the fetch round of group k + 1 is issued BEFORE the stores of group k, into a second set of \
+       registers.  vmcnt retires in order, so the wait for group k + 1's operands then leaves group k's stores in flight; fetched after them \
+       (the plain order) every round waits for the acknowledgement of the previous round's stores plus its own round trip - 4 rounds of \
+       the fp32-residual forms of conv_wide: 54 000 cycles per tile instead of 8 000 (profiles/r04_d_wide_probe.txt). */ \
+    constexpr bool EP_PIPE = (EP_PIPE_V) != 0 && EP_G < EP_WPX; \
+    ep_u4_t ep_raw2[EP_PIPE ? 2 : 1][EP_G][EP_NCI]; float ep_ps2[EP_PIPE ? 2 : 1][EP_G]; \
+    if (EP_PIPE) { EP_FETCH_ROUND(0, 0) } \
 _Pragma("unroll") \
     for (int pg = 0; pg < EP_WPX; pg += EP_G) { \
-    ep_u4_t ep_raw[EP_G][EP_NCI]; float ep_ps[EP_G]; \
-    if (EP_PF && !EP_EARLY && (ep_fetch || ep_has_ps)) { \
-_Pragma("unroll") \
-        for (int g = 0; g < EP_G; ++g) { \
-            int bw, bh, bd, bn; \
-            { int t = (ep_wpx * EP_WPX + pg + g) << 4; bw = t & mW; t >>= lgTW; bh = t & mH; t >>= lgTH; bd = t & mD; t >>= lgTD; bn = t; } \
-            if (!EPFAST && ep_nb + ep_ln + bn >= p.N) continue; \
-            if (ep_has_ps) ep_ps[g] = p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
-            if (ep_fetch) { \
-                const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + \
-                                                            (bw >> ep_rs) * (int)p.res.sW); \
-_Pragma("unroll") \
-                for (int ci = 0; ci < WCH; ci += CSTEP) { \
-                    const int cb = ep_chan(EP_PAIR, CSTEP, n0 + wch * WCH * 16, ci, l4); \
-                    if (!EPALL && cb >= p.Cout) continue; \
-                    if (ep_res32) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const float*)p.res.p + (xb + (unsigned)cb)); \
-                    else if (ep_mr && ep_second(EP_PAIR, ci)) { /* came with the pair's first half */ } \
-                    else if (ep_mr && (EPALL || cb + 4 < p.Cout)) ep_raw[g][(EP_PF ? ci / CSTEP : 0)] = *(const ep_u4_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
-                    else { \
-                        const ep_u2_t q2 = *(const ep_u2_t*)((const half_t*)p.res.p + (xb + (unsigned)cb)); \
-                        ep_raw[g][(EP_PF ? ci / CSTEP : 0)][0] = q2[0]; ep_raw[g][(EP_PF ? ci / CSTEP : 0)][1] = q2[1]; \
-                    } \
-                } \
-            } \
-        } \
-    } \
+    const int ep_bi = EP_PIPE ? ((pg / EP_G) & 1) : 0; \
+    if (!EP_PIPE) { EP_FETCH_ROUND(pg, 0) } \
+    else if (pg + EP_G < EP_WPX) { EP_FETCH_ROUND(pg + EP_G, EP_PIPE ? (((pg / EP_G) + 1) & 1) : 0) } \
+    ep_u4_t (&ep_raw)[EP_G][EP_NCI] = ep_raw2[ep_bi]; float (&ep_ps)[EP_G] = ep_ps2[ep_bi]; \
     if (pg == 0) EP_TL(6); \
 _Pragma("unroll") \
     for (int g = 0; g < EP_G; ++g) { \

@@ -28,6 +28,11 @@
 // 16 consecutive voxels at any alignment, tools/lds_bank_search.py), two buffers of 51 840 B.
 #define EP_GSEL_V EP_GSEL_K      /* position blocks whose residual / mask the epilogue fetches per round: set per instantiation below */
 #define EP_SLICE_FENCE __builtin_amdgcn_sched_barrier(0);
+#define EP_PIPE_V EP_PIPE_K       /* residual fetch rounds issued ahead of the previous round's stores (conv_epilogue.h): set per instantiation below */
+// partial-statistics blocks (64 positions = 16 columns x 4 rows) in the order conv_halo's 16 x 8 tiles give them: ((row block of 8) * tiles per
+// row + tile column) * 2 + half - the finishing kernel adds the partials in block order, so the (mean, rstd) bits are the same on either kernel
+#define EP_BLK_V(sg) ((((th * 2 + ep_wpx) * s.nTW + tw) * 2) + (sg))
+#define EP_NBLK_V (s.nTW * s.nTH * 4)
 #include "conv_epilogue.h"
 #include <cstdlib>
 
@@ -71,7 +76,7 @@ struct WideSched {
     int ncb;           // 256-channel blocks of the layer (1, 2, 4)
     int tg;            // tile groups per XCD = (G / 8) / ncb
     int t8;            // tiles per XCD (contiguous range)
-    int in_bytes;      // bytes the input tensor spans (< 2^31): the DMA's buffer range
+    int in_bytes;      // bytes one sample of the input spans (< 2^31): the DMA's buffer range
 #ifdef W_TL
     unsigned long long* tl; long tl_cap;     // 12 x u64 per wave: cycles in [startup, ring prime, vm wait, barrier, stage, main loop, next-item stage, epilogue], items, chunks, hw id, end time
 #endif
@@ -104,19 +109,19 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
         return (r < s.t8 && t < s.ntiles) ? t : -1;
     };
 
-    const int isN = (int)p.in_sN, isH = (int)p.in_sH, isW = (int)p.in_sW;
+    const int isH = (int)p.in_sH, isW = (int)p.in_sW;
     // ---- halo staging: piece q = tid + 256 * j of a chunk <-> (voxel q / 10, slot q % 10); global -> LDS directly, pad slots are not fetched
     // Buffer-addressed DMA (buffer_load_dwordx4 ... lds): a lane whose byte offset lies outside the buffer gets zeros, so pad slots, voxels
     // outside the image and the lanes of the last piece beyond the image carry a sentinel offset - no zero page, no per-piece address select
     // (two instructions per piece in the K loop: the LDS base into M0 and the load; the chunk's channel offset is the scalar offset).
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, s.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t in_rsrc;                  // the buffer is the sample of the item being staged (set by setup_item)
     constexpr unsigned W_OOB = 0x80000000u;          // launcher: the input spans less than 2^31 bytes
     unsigned poff[W_HI];                             // byte offset of piece j's 16 bytes at channel 0 of the chunk
     auto setup_item = [&](int tile) {                // tile < 0: nothing to stage (every piece is out of range)
         int t = tile < 0 ? 0 : tile;
         const int tw = t % s.nTW; t /= s.nTW;
         const int th = t % s.nTH; t /= s.nTH;
-        const int base = t * isN;
+        in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)t * p.in_sN), 0, s.in_bytes, 0x00020000);
         // (the thread index goes through an opaque move: otherwise the item-invariant part of this addressing - 3 values per piece - is hoisted
         // out of the item loop and held in registers across the main loop, and the kernel spills)
         int tid_o = tid;
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
             const int hh = hv / W_HW, hw = hv % W_HW;
             const int ih = th * 16 + hh - 1, iw = tw * 16 + hw - 1;
             const bool inb = tile >= 0 && q < W_NPIECE && sl < 8 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            poff[j] = inb ? (unsigned)(base + __mul24(ih, isH) + __mul24(iw, isW) + sl * 8) * 2u : W_OOB;
+            poff[j] = inb ? (unsigned)(__mul24(ih, isH) + __mul24(iw, isW) + sl * 8) * 2u : W_OOB;
         }
     };
     // piece j of a chunk, asynchronous (vmcnt): awaited by the counted wait + barrier at the chunk's head.  Every lane takes part (no exec
@@ -298,7 +303,12 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
         // ---- epilogue (conv_epilogue.h): the tensor combination is a compile-time constant.  Stores are not waited for here.
         {
             constexpr bool EP_HEAVY = false, EP_EARLY = false;
-            constexpr int EP_GSEL_K = 8;      // every fetch of the wave's tile before its first store (2 / 4 blocks per round spill: hipcc carries more addressing then)
+            // position blocks whose residual / mask is fetched per round, and whether the rounds are pipelined (the next round's fetch ahead of
+            // this round's stores, two register sets): the whole tile in one round where no residual is read; with a residual 2 blocks per
+            // round (1 for the fp32 residual of the non-blend form: 32 registers per block), pipelined.  No scratch in any instantiation.
+            constexpr bool EP_HASRES = (EPC & 3) != 0;
+            constexpr int EP_GSEL_K = !EP_HASRES ? 8 : (MODE == MODE_STD && (EPC & 3) == 2) ? 1 : (MODE == MODE_SPADE ? 8 : (MODE == MODE_STDSTAT ? 1 : 2));
+            constexpr int EP_PIPE_K = EP_HASRES && MODE != MODE_SPADE ? 1 : 0;
             constexpr int EP_WPX = WPX;
             constexpr int lgTW = 4, lgTH = 4, lgTD = 0, lgS = 8, mW = 15, mH = 15, mD = 0;
             const int ep_wpx = wp;
@@ -346,6 +356,22 @@ int launch_wide_inst(const ConvParams& p, const WideSched& s, int grid, hipStrea
     return 0;
 }
 
+// the instantiations: (mode, tensor combination) of the engine's wide 3x3 layers
+//   T blend conv1 / conv2 (adaptive_modulate.py:337-349) | R's 2-D pair (util.py:120-128), W.third | G 3x3 convs with the next norm's statistics,
+//   without / with the block's fp16 residual (util.py:329-344) | SPADE gamma / beta convs (util.py:295-302)
+constexpr int WIDE_NINST = 7;
+constexpr int WIDE_INST[WIDE_NINST][2] = {
+    {MODE_TBLEND, EP_CODE(0, 1, 0, 0, 1)}, {MODE_TBLEND, EP_CODE(2, 1, 1, 1, 1)},
+    {MODE_STD, EP_CODE(0, 1, 0, 0, 0)}, {MODE_STD, EP_CODE(2, 1, 1, 1, 0)},
+    {MODE_STDSTAT, EP_CODE(0, 1, 0, 0, 0)}, {MODE_STDSTAT, EP_CODE(1, 1, 0, 0, 0)},
+    {MODE_SPADE, EP_CODE(1, 1, 0, 0, 0)},
+};
+int wide_inst_of(int mode, int code)
+{
+    for (int i = 0; i < WIDE_NINST; ++i) if (WIDE_INST[i][0] == mode && WIDE_INST[i][1] == code) return i;
+    return -1;
+}
+
 int wide_ep_code(const ConvParams& p)
 {
     return EP_CODE(p.res.p ? (p.res_f32 ? 2 : 1) : 0, p.out0.p ? 1 : 0, p.out0_f32 ? 1 : 0, p.out1.p ? 1 : 0, p.pixscale ? 1 : 0);
@@ -359,7 +385,10 @@ bool conv_wide_supported(const ConvParams& p, int mode)
 {
     if (p.KD != 1 || p.KH != 3 || p.KW != 3 || p.D != 1 || p.inD != 1 || p.up_shift || p.cg || p.hilo || p.ragged || p.sk_out || p.kw_out || p.xf_kind) return false;
     if (p.H % 16 || p.W % 16 || p.Cin % 64 || p.Cout_pad % 256 || p.Cout_pad > 1024) return false;
-    if (p.stat_out || p.ep_general) return false;
+    if (p.ep_general) return false;
+    if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
+    if ((mode == MODE_STDSTAT) != (p.stat_out != nullptr)) return false;
+    if (mode == MODE_SPADE && (!p.res.p || p.res_f32 || !p.stats || !p.bias || !p.bias2)) return false;
     const int cstep = (mode == MODE_TBLEND || mode == MODE_SPADE) ? 2 : 1;
     if (p.Cout * cstep != p.Cout_pad || (p.Cout & 7)) return false;
     const int ncb = p.Cout_pad / 256;
@@ -368,9 +397,9 @@ bool conv_wide_supported(const ConvParams& p, int mode)
     auto al8 = [](const TDesc& t) { return (((unsigned long long)t.p & 15ull) == 0) && (((t.sN | t.sD | t.sH | t.sW) & 7) == 0); };
     if ((p.res.p && !p.res_f32 && !al8(p.res)) || (p.out0.p && !p.out0_f32 && !al8(p.out0)) || (p.out1.p && !al8(p.out1))) return false;
     if (((unsigned long long)p.in & 15ull) || ((p.in_sN | p.in_sH | p.in_sW) & 7)) return false;
-    const int code = wide_ep_code(p);
-    if (mode == MODE_TBLEND) return code == EP_CODE(0, 1, 0, 0, 1) || code == EP_CODE(2, 1, 1, 1, 1);
-    return false;
+    // a sample of the input is addressed with 31-bit byte offsets, its axis products are 24-bit multiplies
+    if ((long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW + p.Cin >= (1L << 30) || p.in_sH >= (1L << 23) || p.in_sW >= (1L << 23)) return false;
+    return wide_inst_of(mode, wide_ep_code(p)) >= 0;
 }
 
 int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st)
@@ -379,8 +408,7 @@ int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st)
     {
         if (ep_check_extents(p, "conv_wide")) return -1;
     }
-    const long in_span = (long)(p.N - 1) * p.in_sN + (long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW + p.Cin;
-    if (in_span >= (1L << 30) || p.in_sH >= (1L << 23) || p.in_sW >= (1L << 23)) { cs_set_error("conv_wide: input too large for 31-bit byte offsets / 24-bit axis products"); return -1; }
+    const long in_span = (long)(p.H - 1) * p.in_sH + (long)(p.W - 1) * p.in_sW + p.Cin;      // one sample
     WideSched s;
     s.in_bytes = (int)(in_span * 2);
     s.nTW = p.W / 16; s.nTH = p.H / 16;
@@ -393,10 +421,13 @@ int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st)
     s.tl = g_wide_tl; s.tl_cap = g_wide_tl_cap;
 #endif
     ConvParams kp = p;
+    if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
     const int code = wide_ep_code(p);
-    if (mode == MODE_TBLEND) {
-        if (code == EP_CODE(0, 1, 0, 0, 1)) return launch_wide_inst<MODE_TBLEND, EP_CODE(0, 1, 0, 0, 1)>(kp, s, G, st);
-        if (code == EP_CODE(2, 1, 1, 1, 1)) return launch_wide_inst<MODE_TBLEND, EP_CODE(2, 1, 1, 1, 1)>(kp, s, G, st);
+    switch (wide_inst_of(mode, code)) {
+#define WIDE_CASE(i) case i: return launch_wide_inst<WIDE_INST[i][0], WIDE_INST[i][1]>(kp, s, G, st);
+        WIDE_CASE(0) WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6)
+#undef WIDE_CASE
+        default: break;
     }
     cs_set_error("conv_wide: no instantiation for mode %d / epilogue code %d", mode, code);
     return -1;

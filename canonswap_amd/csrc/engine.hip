@@ -22,7 +22,9 @@ void cs_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* cs_last_error(void) { return g_err; }
-extern "C" int cs_abi_version(void) { return 1; }
+// 2 (round 4): cs_conv_desc grew (hilo, stat_out, xf_*, ep_general), cs_op_conv takes conv_halo / vol32 / conv_wide configurations only, the
+// packed weight blobs of F.down0 / down1 / second carry [W_hi | W_lo], W.occ49 exists.  _lib.load() refuses any other value.
+extern "C" int cs_abi_version(void) { return CS_ABI_VERSION; }
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
 
@@ -343,6 +345,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
         c.p.ep_general = epg;
         if (conv_wide_supported(c.p, c.mode) && (long)c.p.N * (c.p.H / 16) * (c.p.W / 16) * (c.p.Cout_pad / 256) >= 512) {
+            c.stat_nblk = (c.p.W / 16) * (c.p.H / 8) * 2;      // partial-statistics blocks per sample: 64 positions each, in the 16 x 8 tiles' order
             TRY(e->run(0, st, [&] { return launch_conv_wide(c.p, c.mode, st); }, c.name, fl));
             return amax_after(e, c, st);
         }
@@ -534,13 +537,14 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 
 // ------------------------------------------------------------------------------------------------ W
 // DenseMotionNetwork.forward (dense_motion.py:67-104). feat: fp32 HWDC. Leaves deformation / occlusion in
-// e->dm_deform / e->dm_occ.
+// e->dm_deform / e->dm_occ (the deformation only when the fused kernel is not used or the caller wants it: in the fused kernel it lives in LDS
+// and going through HBM as well would be 0.79 MB per frame and call for nothing - ADVICE r3).
 // warp_in / warp_o32 / warp_o16: when given, the feature warp that consumes the deformation (warping_network.py:46-62) is part of the softmax
 // kernel (dm_softmax_warp_kernel): the caller launches no grid_sample.
 bool warp_fused() { static const bool on = [] { const char* s = getenv("CANONSWAP_WARP_FUSED"); return !s || atoi(s) != 0; }(); return on; }
 
 int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st,
-                     const float* warp_in = nullptr, float* warp_o32 = nullptr, half_t* warp_o16 = nullptr)
+                     const float* warp_in = nullptr, float* warp_o32 = nullptr, half_t* warp_o16 = nullptr, bool want_deform = false)
 {
     TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, B, FD, FH, FW, st); }, "dm_compress"));
     e->flops += 2.0 * 32 * 4 * VOX * B;
@@ -604,7 +608,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         TRY(go(e, m, st, wide ? 8 : 2, 8));
     }
     if (warp_in && !mask_out && warp_fused()) {
-        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, e->dm_deform, B, FD, FH, FW, st, compact); },
+        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, want_deform ? e->dm_deform : nullptr, B, FD, FH, FW, st, compact); },
                    "dm_softmax_warp"));
     } else {
         TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st, compact); }, "dm_softmax"));
@@ -1353,7 +1357,7 @@ extern "C" int cs_warp_forward(cs_engine* e, int B, const float* f, const float*
     ENTER(e, B);
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, B, f, e->vs[0], nullptr, st));
-    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st, e->vs[0], nullptr, e->va[0]));      // dense motion + the feature warp it drives
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st, e->vs[0], nullptr, e->va[0], deformation_out != nullptr));      // dense motion + the feature warp it drives
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     if (seg_out) TRY(e->run(1, st, [&] { return launch_nhwc16_to_nchw(e->seg16, seg_out, B, 256, 4096, st); }, "nhwc16_to_nchw"));
     if (occ_out) TRY(copy_dd(occ_out, e->dm_occ, (size_t)B * 4096 * 4, st));

@@ -48,8 +48,8 @@ __global__ void __launch_bounds__(256) se_conv_kernel(const float* __restrict__ 
 }
 
 // max over the pixels below the threshold (crop.py:45: `x[~mask].max()` runs over the WHOLE (N,1,H,W) tensor, not per sample -
-// ADVICE r2); two deterministic stages (max is order independent): per-(sample, block) partials, then every thread of the final
-// pass reduces all N x nparts of them
+// ADVICE r2); two deterministic stages (max is order independent): per-(sample, block) partials, then every workgroup of the final
+// pass reduces all N x nparts of them once
 __global__ void __launch_bounds__(256) se_max_kernel(const float* __restrict__ x, long P, float thr, float* __restrict__ part)
 {
     const int n = blockIdx.y;
@@ -69,8 +69,16 @@ __global__ void __launch_bounds__(256) se_final_kernel(float* __restrict__ x, lo
                                                        unsigned char* __restrict__ hard)
 {
     const int n = blockIdx.y;
+    // nparts = blocks x samples: the maximum over the whole batch.  One cooperative pass per workgroup (threads stride over the partials,
+    // wave butterfly, four wave results through LDS) instead of every thread looping over all of them (4096 broadcast loads per thread at
+    // 64 frames: ADVICE r3); max is order independent, so the value is the same.
+    __shared__ float sm[4];
     float m = -INFINITY;
-    for (int i = 0; i < nparts; ++i) m = fmaxf(m, part[i]);          // nparts = blocks x samples: the maximum over the whole batch
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float v = x[(long)n * P + i];

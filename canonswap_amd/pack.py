@@ -101,8 +101,13 @@ def _resblocks3d(out, prefix, sd):
 
 
 def _hi_lo(w):
-    """[Cout][Cin][...] -> [Cout][2 Cin][...] = [W_hi | W_lo] (both fp16-representable, W_hi + W_lo == W to 2^-22): split-precision weights for a
-    conv whose launch reads its input channels twice (engine.hip: wsplit_in), out = W_hi x + W_lo x."""
+    """[Cout][Cin][...] -> [Cout][2 Cin][...] = [W_hi | W_lo] (both fp16-representable): split-precision weights for a conv whose launch reads
+    its input channels twice (engine.hip: wsplit_in), out = W_hi x + W_lo x.
+
+    Accuracy: W_hi + W_lo == W to 2^-22 relative for |w| >= 2^-3.  Below that W_lo (<= 2^-11 |w|) is an fp16 SUBNORMAL, i.e. quantised at 2^-24
+    absolute: W_hi + W_lo == W to 2^-25 absolute - for the |w| ~ 1e-2 of these layers about 2^-18 relative, still 7 bits beyond W_hi alone.  The
+    scheme therefore relies on v_mfma_f32_16x16x32_f16 consuming fp16 denormal inputs exactly (it does not flush them, whatever the wave's
+    denormal mode); tests/test_gpu_ops.py::test_conv_split_weights_use_fp16_subnormals holds that fact against a float64 convolution (ADVICE r3)."""
     w = np.asarray(w, np.float64)
     hi = w.astype(np.float16).astype(np.float64)
     lo = (w - hi).astype(np.float16).astype(np.float64)

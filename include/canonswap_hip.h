@@ -26,6 +26,7 @@ typedef struct cs_engine cs_engine;
 int cs_create(int device_id, int max_batch, cs_engine** out);   /* 1 <= max_batch <= 64; workspace ~0.35 GB per frame of batch */
 void cs_destroy(cs_engine* e);
 const char* cs_last_error(void);
+#define CS_ABI_VERSION 2       /* bumped whenever a struct of this header, an entry point's meaning or the weight blob format changes */
 int cs_abi_version(void);
 /* Upload one packed weight blob (host pointer).  Names/layouts are produced by canonswap_amd/pack.py from
  * the reference's state-dict keys (BatchNorm / spectral norm folded, channels-last, fp16 MFMA order). */

@@ -411,3 +411,29 @@ def test_conv_ragged_last_chunk_paired_taps(k, tile, cfg, cout_pad, cin_real, ci
         assert Cout == cout_pad or float(out[..., Cout:].abs().max()) == 0.0
         outs.append(out.cpu())
     assert ops.rel_err(outs[1], outs[0]) < 1e-5          # fp32 accumulation, another order within the last chunk
+
+
+def test_conv_split_weights_use_fp16_subnormals():
+    """pack._hi_lo: for |w| < 2^-3 the W_lo half of a split-precision weight is an fp16 subnormal.  The MFMA must consume it exactly: the conv
+    over [x | x] with [W_hi | W_lo] then matches a float64 conv with the unrounded weights to ~2^-18 relative; flushed to zero it would be
+    W_hi alone, 2^-11."""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(77)
+    N, Cin, Cout, S = 1, 64, 64, 32
+    x = torch.from_numpy(r.standard_normal((N, Cin, S, S)).astype(np.float16))
+    w = (0.01 * r.standard_normal((Cout, Cin, 3, 3))).astype(np.float64)                     # |w| ~ 1e-2: every W_lo is subnormal
+    hl = pack._hi_lo(w)
+    lo = hl[:, Cin:]
+    assert np.abs(lo[lo != 0]).max() < 2.0 ** -14                                             # subnormal range of fp16
+    ref = F.conv2d(x.double(), torch.from_numpy(w), None, padding=1)
+    ref_hi = F.conv2d(x.double(), torch.from_numpy(hl[:, :Cin]), None, padding=1)
+    xd = torch.cat([x, x], dim=1).permute(0, 2, 3, 1).contiguous().unsqueeze(1).to(DEV)      # [N, 1, H, W, 2 Cin]
+    wp = torch.from_numpy(pack.pack_conv(hl, Cout)).to(DEV)
+    out = torch.zeros(N, 1, S, S, Cout, dtype=torch.float32, device=DEV)
+    ops.conv(xd, wp, Cout, Cout, (1, 3, 3), out0=out, cfg=-2)
+    torch.cuda.synchronize()
+    got = out.cpu()[:, 0].permute(0, 3, 1, 2).double()
+    err = float((got - ref).norm() / ref.norm()); err_hi = float((ref_hi - ref).norm() / ref.norm())
+    assert err_hi > 1e-4                     # what a flush of the subnormals would leave
+    assert err < 2e-6, (err, err_hi)         # fp32 accumulation of 1152 products + 2^-18-relative weights

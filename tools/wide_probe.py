@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--cfgs", default="17,31")
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     B, Cc = a.batch, 512
     r = np.random.Generator(np.random.PCG64(3))
@@ -46,13 +47,23 @@ def main():
     o32 = torch.empty(B, 1, 64, 64, Cc, dtype=torch.float32, device=DEV)
     s2 = torch.rand(Cc, device=DEV) + 0.5
     gfl = 2 * 9 * Cc * 2 * Cc * B * 4096 / 1e9
+    wps = torch.from_numpy(pack.pack_conv(w[:Cc], Cc)).to(DEV)
+    res16 = res.half()
+    so = torch.empty(B * 4 * 8 * 2 * Cc * 2, dtype=torch.float32, device=DEV)
     for cfg in [int(c) for c in a.cfgs.split(",")]:
         cases = {
-            "conv1 (blend, relu, fp16 out)": lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, act0="relu", out0=o16, mode=1, cfg=cfg),
-            "conv2 (blend, fp32 res, fp32 + fp16 out)": lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, res=res, out0=o32,
-                                                                          s2=s2, t2=bias, act1="relu", out1=o16, mode=1, cfg=cfg),
+            "T conv1 (blend, relu, fp16 out)": (1.0, lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, act0="relu", out0=o16, mode=1, cfg=cfg)),
+            "T conv2 (blend, fp32 res, fp32 + fp16 out)": (1.0, lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, res=res, out0=o32,
+                                                                                 s2=s2, t2=bias, act1="relu", out1=o16, mode=1, cfg=cfg)),
+            "R c1 (lrelu, fp16 out)": (0.5, lambda: ops.conv(x, wps, Cc, Cc, (1, 3, 3), bias=bias, act0="lrelu", slope0=0.01, out0=o16, cfg=cfg)),
+            "R c2 (fp32 res, fp32 + fp16 out)": (0.5, lambda: ops.conv(x, wps, Cc, Cc, (1, 3, 3), bias=bias, res=res, out0=o32, s2=s2, t2=bias, act1="lrelu", slope1=0.01,
+                                                                       out1=o16, cfg=cfg)),
+            "G c0 (fp16 out + statistics)": (0.5, lambda: ops.conv(x, wps, Cc, Cc, (1, 3, 3), bias=bias, out0=o16, stat_out=so, cfg=cfg)),
+            "G c1 (fp16 res, fp16 out + statistics)": (0.5, lambda: ops.conv(x, wps, Cc, Cc, (1, 3, 3), bias=bias, res=res16, out0=o16, stat_out=so, cfg=cfg)),
         }
-        for name, fn in cases.items():
+        for name, (fscale, fn) in cases.items():
+            if a.only and a.only not in name:
+                continue
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
@@ -63,7 +74,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
-            print(f"cfg {cfg} {name:42s} {us:8.1f} us/launch  {gfl / us * 1e-3:7.1f} TFLOP/s ({gfl / us * 1e-3 / 2500:.3f} of peak)")
+            print(f"cfg {cfg} {name:42s} {us:8.1f} us/launch  {fscale * gfl / us * 1e3:7.1f} TFLOP/s ({fscale * gfl / us * 1e3 / 2500:.3f} of peak)")
             if tl is not None and cfg == 31:
                 tl.zero_()
                 fn()
