@@ -339,9 +339,12 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     }
     if (c.p.xf_kind) { cs_set_error("%s: transform staging needs the vol32 kernel", c.name); return -1; }
     // the wide 2-D 3x3 convs on the persistent kernel (conv_wide.hip: 256 x 256 workgroup tiles, 8 x 8 fragments per wave, one workgroup per
-    // CU) once every workgroup of its grid gets two items or more; the same bits as conv_halo (CANONSWAP_WIDE=0: A/B knob)
+    // CU) once every workgroup of its grid gets two items or more; the same bits as conv_halo (CANONSWAP_WIDE=0: A/B knob).  The SPADE
+    // gamma / beta convs stay on conv_halo's 128 x 256 tiles (CANONSWAP_WIDE=2 moves them too): their K is two chunks (Cin = 128), so a tile
+    // is 40 % epilogue, which two resident workgroups overlap and one persistent workgroup per CU cannot: 1.01 - 1.04x the time
+    // (profiles/r04_c_ab_wide.txt).
     static const int wide_on = [] { const char* s = getenv("CANONSWAP_WIDE"); return s ? atoi(s) : 1; }();
-    if (wide_on && !e->latency_mode && c.hcfg < 0) {
+    if (wide_on && !e->latency_mode && c.hcfg < 0 && (c.mode != MODE_SPADE || wide_on >= 2)) {
         static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
         c.p.ep_general = epg;
         if (conv_wide_supported(c.p, c.mode) && (long)c.p.N * (c.p.H / 16) * (c.p.W / 16) * (c.p.Cout_pad / 256) >= 512) {
