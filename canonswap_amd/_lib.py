@@ -171,22 +171,28 @@ def isa_check(obj_dir: str | None = None) -> dict:
 
 
 def _isa_check_wide(obj_dir: str, objdump: str) -> dict:
-    """conv_wide.hip streams its weight ring with untracked inline-asm loads and waits with counted `s_waitcnt vmcnt(N)` that name the slot's
-    registers.  Check in the disassembly of every conv_wide kernel: each MFMA's weight operand (src0) is a VGPR quadruple whose last writer
-    is a `global_load_dwordx4` (never a copy of one: a copy made before the data landed would be stale) with a vmcnt wait between that load
-    and the MFMA; 18 K-steps x 64 MFMAs per kernel."""
+    """conv_wide.hip and the 256 x 160 tiles of conv_halo (ASMR) stream their weight ring with untracked inline-asm loads and wait with
+    counted `s_waitcnt vmcnt(N)` that name the slot's registers.  Check in the disassembly of every such kernel: each MFMA's weight operand
+    (src0) is a VGPR quadruple whose last writer is a `global_load_dwordx4` (never a copy of one: a copy made before the data landed would
+    be stale) with a vmcnt wait between that load and the MFMA; conv_wide: 18 K-steps x 64 MFMAs per kernel."""
+    seen = _isa_check_ring(obj_dir, objdump, "conv_wide.o", r"\S*conv_wide_kernel\S*", 18 * 64)
+    seen.update(_isa_check_ring(obj_dir, objdump, "conv_halo_g1.o", r"_Z16conv_halo_kernelILi32ELi8ELi5ELi2ELi2ELi0ELb1ELb0ELi[78]E\S*", None))
+    return seen
+
+
+def _isa_check_ring(obj_dir: str, objdump: str, oname: str, name_re: str, expect_mfma) -> dict:
     import re
-    obj = os.path.join(obj_dir, "conv_wide.o")
+    obj = os.path.join(obj_dir, oname)
     subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True)
     co = obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950"
     try:
         txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
     finally:
         for f in os.listdir(obj_dir):
-            if f.startswith("conv_wide.o.0."):
+            if f.startswith(oname + ".0."):
                 os.remove(os.path.join(obj_dir, f))
     seen = {}
-    for m in re.finditer(r"^[0-9a-f]+ <(\S*conv_wide_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
+    for m in re.finditer(r"^[0-9a-f]+ <(" + name_re + r")>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         writer, waited, nmfma = {}, {}, 0
         for l in body:
@@ -217,11 +223,11 @@ def _isa_check_wide(obj_dir: str, objdump: str) -> dict:
                 for r in rng:
                     writer[r] = op
                     waited[r] = False
-        if nmfma != 18 * 64:
-            raise RuntimeError(f"isa_check: {name}: {nmfma} MFMAs in the kernel, expected 18 K-steps x 64")
+        if expect_mfma is not None and nmfma != expect_mfma:
+            raise RuntimeError(f"isa_check: {name}: {nmfma} MFMAs in the kernel, expected {expect_mfma}")
         seen[name] = nmfma
     if not seen:
-        raise RuntimeError("isa_check: no conv_wide kernel found in conv_wide.o (name mangling changed?)")
+        raise RuntimeError(f"isa_check: no kernel matching {name_re} found in {oname} (name mangling changed?)")
     return seen
 
 

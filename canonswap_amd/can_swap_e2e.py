@@ -53,15 +53,16 @@ class _Callable:
 class can_swapper(object):
     """MI355X engine behind the reference's ``can_swapper`` interface."""
 
-    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8, id_net=None, fp8_weights: bool = False,
-                 latency_mode: bool = False):
+    def __init__(self, inference_cfg=None, state_dicts=None, max_batch: int = 8, id_net=None, latency_mode: bool = False,
+                 packed_blobs=None):
+        """packed_blobs: the result of pack.build_blobs() for the same state-dicts, when another process of this node already ran the
+        load-time weight transform (engine.load_blobs)."""
         self.inference_cfg = inference_cfg
         self.device_id = getattr(inference_cfg, "device_id", 0)
         self.compile = False                      # torch.compile switch of the reference (:47,:74-77) has no meaning here
         if getattr(inference_cfg, "flag_force_cpu", False):
             raise RuntimeError("flag_force_cpu=True: this engine runs on an MI355X only (no CPU path)")
         self.device = "cuda:" + str(self.device_id)
-        self.fp8_weights = fp8_weights            # BASELINE configs[4]: conv weights quantised to e4m3 (per-out-channel scale)
         self.engine = Engine(self.device_id, max_batch=max_batch, latency_mode=latency_mode)
         self.appearance_feature_extractor = _Callable(self.engine.extract_feature_3d)
         self.warping_module = _WarpingModule(self.engine)
@@ -75,7 +76,11 @@ class can_swapper(object):
         arc = "pretrained_weights/arcface_checkpoint.tar"
         if self.netArc is None and os.path.exists(arc):
             self.netArc = torch.load(arc, map_location=torch.device("cpu"), weights_only=False).to(self.device).eval()
-        if state_dicts is not None:
+        if packed_blobs is not None:
+            if any(k.startswith("M.") for k in packed_blobs):
+                self.motion_extractor = _Callable(self.engine.motion_extract)
+            self.engine.load_blobs(packed_blobs)
+        elif state_dicts is not None:
             self.load_state_dicts(state_dicts)
         else:
             self.load_cpk()
@@ -91,7 +96,7 @@ class can_swapper(object):
         if "motion_extractor" in combined:
             keys.append("motion_extractor")
             self.motion_extractor = _Callable(self.engine.motion_extract)
-        self.engine.load_state_dicts({k: combined[k] for k in keys}, fp8_weights=self.fp8_weights)
+        self.engine.load_state_dicts({k: combined[k] for k in keys})
 
     # ---- small helpers kept for interface parity
     def inference_ctx(self):

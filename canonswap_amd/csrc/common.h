@@ -111,6 +111,7 @@ struct ConvParams {
     float* kw_out;
     // tests / A/B (CANONSWAP_EP_GENERAL=1): run the general epilogue where the kernel also carries branch-free copies (conv_epilogue.h)
     int ep_general;
+    unsigned in_sample_bytes;   // conv_halo's 256 x 160 tiles (set by the launcher): bytes one sample of the input spans, the range of their buffer-addressed halo DMA
     int xf_kind;
     TDesc xf_y, xf_res, xf_out;
     const float* xf_stats; const float* xf_gamma; const float* xf_beta;

@@ -17,6 +17,7 @@
 // LDS image: [halo voxel][CK channels] fp16, voxel stride CK*2+16 bytes.
 #pragma once
 #include <type_traits>
+#include <utility>
 #include <cstdlib>
 #include "common.h"
 #ifdef CS_TIMELINE
@@ -118,6 +119,42 @@ template <int ST, int PAD> __device__ __forceinline__ int halo_lane_pos(int l)
     if (SS::LW == 2 && PAD == 2) return ((l & 1) << 1) | ((l & 2) << 2) | ((l >> 2) & 1) | ((l & 8) >> 1);      // bits (1,3,0,2)
     return ((l & 1) << 1) | ((l & 2) << 1) | ((l >> 2) & 1) | (l & 8);                                          // bits (1,2,0,3)
 #endif
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) - the K-steps of the ASMR kernels need
+// their index as a constant expression (the counted waits are instruction immediates)
+template <class F, int... I> __device__ __forceinline__ void halo_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void halo_static_for(F&& f) { halo_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// ASMR kernels: VMEM instructions younger than the ring loads of K-step `st` at the moment that step starts.  Issue order of a chunk of L steps:
+// step u >= 1 reloads (WCH loads) the slot step u - 1 used, then - if the chunk stages a next one and ST0 <= u < ST0 + HI - issues one DMA
+// piece; behind the last step the slot it used is reloaded.  A reload at step u fetches step u - 1 + PFS of the same chunk, or - past its end -
+// the step of the NEXT chunk that slot serves there (L % PFS == 0: steps 0, 1, ... in order; else step (u - 1) % PFS).  The same code runs as
+// the first chunk of a tile (ring primed with steps 0 .. PFS - 1 in order, behind the staging burst) and behind a full chunk of NP steps
+// that staged pieces: the smaller count (the stronger wait) of the two cases is used.
+template <int WCH, int PFS, int HI, int ST0>
+constexpr int halo_ring_young(int st, int L, int NP, bool dma_cur)
+{
+    auto dma = [&](int u, bool on) { return (on && u >= ST0 && u < ST0 + HI) ? 1 : 0; };
+    // events of the current chunk before step st starts, younger than a given point
+    auto cur_before = [&](int from_step /* events of steps from_step .. st - 1 */) {
+        int n = 0;
+        for (int u = from_step; u < st; ++u) n += (u >= 1 ? WCH : 0) + dma(u, dma_cur);
+        return n;
+    };
+    if (st >= PFS) {
+        const int u0 = st - PFS + 1;                      // reload group of step u0 fetched step st
+        return dma(u0, dma_cur) + cur_before(u0 + 1);
+    }
+    // fetched before the chunk: (a) primed, (b) carried from the previous chunk
+    const int prime = (PFS - 1 - st) * WCH + cur_before(0);
+    int g = 0;                                            // reload group (1 .. NP) of the previous chunk that fetched this chunk's step st
+    if (NP % PFS == 0) g = st + NP - PFS + 1;
+    else { for (int u = NP - PFS + 1; u <= NP; ++u) if ((u - 1) % PFS == st) g = u; }
+    int carried = dma(g, true);
+    for (int u = g + 1; u <= NP; ++u) carried += WCH + (u < NP ? dma(u, true) : 0);
+    carried += cur_before(0);
+    return prime < carried ? prime : carried;
 }
 
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
@@ -344,6 +381,138 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #endif
 #endif
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;
+        // ---- ASMR: the 256 x 160 tiles (hourglass tail, mask conv: one workgroup per CU, one wave per SIMD) stream their weight ring with
+        // loads the compiler does not track and stage the next chunk's halo piece by piece UNDER the MFMAs, through buffer-addressed LDS
+        // DMA - conv_wide.hip's scheme (see there) inside this kernel's tile / epilogue machinery.  With compiler-tracked loads every wait
+        // for a weight fragment becomes vmcnt(0) while an LDS DMA is in flight, so the halo could only be staged as a burst of 15 pieces
+        // at the chunk's head (13 % of a tail chunk) followed by a full drain.  Same K order, same bits.
+#ifdef CS_NO_ASMRING
+        constexpr bool ASMR = false;
+#else
+        constexpr bool ASMR = DB && WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8) && MODE == MODE_STD && PFS == 3;
+#endif
+        if constexpr (ASMR) {
+            static_assert(SK == false && KH32 == 1, "ASMR: 32-channel chunks");
+            constexpr int HSTRIDE = HI * 4096;       // LDS bytes between the two buffers: the last piece's lanes beyond the image land in the gap
+            constexpr int ST0 = 1;                   // K-steps ST0 .. ST0 + HI - 1 of a chunk each issue one DMA piece of the next chunk
+            constexpr unsigned OOB = 0x80000000u;    // byte offset outside the buffer (the launcher keeps a sample below 2^31 bytes): the lane reads zeros
+            // per-sample buffer: pad slots, voxels outside the volume, lanes beyond the image and channels beyond Cin carry OOB
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)nb * p.in_sN), 0, (int)p.in_sample_bytes, 0x00020000);
+            unsigned poffb[HI];
+#pragma unroll
+            for (int j = 0; j < HI; ++j) {
+                const int q = tid + 256 * j;
+                const int hv = q / SLP, sl = q % SLP;
+                const int hw = hv % HW; int r = hv / HW;
+                const int hh = r % HH; r /= HH;
+                const int id = d0 + r - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW;
+                const bool inb = q < nitems && sl < SL && r < HD && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                poffb[j] = inb ? (unsigned)(__mul24(id, isD) + __mul24(ih >> p.up_shift, isH) + __mul24(iw >> p.up_shift, isW) + sl * 8) * 2u : OOB;
+            }
+            // piece j of chunk cn (cn >= cc_hi: nothing to stage, every lane out of range)
+            auto stage_piece = [&](int buf, int cn, int j) {
+                const int c0 = cn * CK;
+                const int climit = cn < cc_hi ? p.Cin - c0 : 0;                  // channels of that chunk that exist
+                const unsigned off = (((tid + 256 * j) % SLP) * 8 < climit) ? poffb[j] : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (size_t)buf * HSTRIDE + (size_t)(256 * j + wave * 64) * 16),
+                                                         16, (int)off, c0 * 2, 0, 0);
+            };
+            u4_t wr[PFS][WCH];
+            auto wsrc_of = [&](int cc, int st, int nsc) -> const half_t* {       // st may run past the chunk (the carried fetches)
+                int c2 = cc, s2 = st;
+                if (st >= nsc) { c2 = cc + 1; s2 = (nsc % PFS == 0) ? st - nsc : (st - PFS) % PFS; }      // the slot a step frees serves that step of the next chunk
+                const int ccl = c2 < nck ? c2 : nck - 1;                         // behind the last chunk the fetches repeat and are dropped
+                return wlane + (long)(ccl * NT + s2) * wstep;
+            };
+            auto wload1 = [&](u4_t& dst, const half_t* src, int ci) {            // ci: compile-time after unrolling; EP_PAIR == 0 here: rows ci * 16
+                if (ci == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src));
+                else if (ci == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(dst) : "v"(src));
+                else if (ci == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(dst) : "v"(src));
+                else if (ci == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(dst) : "v"(src));
+                else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src + 4 * 16 * 32));
+            };
+            static_assert(EP_PAIR == 0, "ASMR: plain weight row order");
+            TL_STAMP(1);
+#pragma unroll
+            for (int j = 0; j < HI; ++j) stage_piece(0, cc_lo, j);
+#pragma unroll
+            for (int st = 0; st < PFS; ++st)
+#pragma unroll
+                for (int ci = 0; ci < WCH; ++ci) wload1(wr[st][ci], wsrc_of(cc_lo, st, NS), ci);
+            TL_STAMP(2);
+            int gbuf = 0;
+            auto run_chunk_a = [&](int cc, auto rag_t) {
+                constexpr bool RAG = decltype(rag_t)::value;
+                // head: this chunk's halo has landed - this wave's pieces by the counted wait (the PFS * WCH ring fetches are younger), everyone's by
+                // the barrier, which also says that everyone has left the other buffer
+                wait_vmcnt_le<PFS * WCH>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned char* hb = smem + (size_t)gbuf * HSTRIDE;
+                const int nbuf = gbuf ^ 1;
+                gbuf ^= 1;
+                constexpr int HA = WPX / 2;
+                constexpr int PK = SS::KW > 1 ? SS::KW : SS::KH, SPR = PK / 2 + PK % 2;
+                constexpr int NSC = RAG ? (NT / PK) * SPR : NS;
+                auto tap_of = [&](int st) -> int { return RAG ? (st / SPR) * PK + 2 * (st % SPR) : st; };
+                auto paired = [&](int st) -> bool { return RAG && (st % SPR) < PK / 2; };
+                auto toff_of = [&](int st) -> int {
+                    const int tap = tap_of(st);
+                    return (((tap / (SS::KW * SS::KH)) * SHH + (tap / SS::KW) % SS::KH) * SHW + tap % SS::KW) * VS;
+                };
+                int abP[RAG ? WPX : 1];
+                if constexpr (RAG) {
+                    const int pd = (l4 >= 2) ? (SS::KW > 1 ? VS : SHW * VS) - 32 : 0;
+#pragma unroll
+                    for (int pi = 0; pi < WPX; ++pi) abP[pi] = abase[pi] + pd;
+                }
+                auto ab_of = [&](int pi, int st) -> int { return paired(st) ? abP[RAG ? pi : 0] : abase[pi]; };
+                h8_t afA[HA], afB[WPX - HA];
+#pragma unroll
+                for (int pi = 0; pi < HA; ++pi) afA[pi] = *(const h8_t*)(hb + ab_of(pi, 0) + toff_of(0));
+                halo_static_for<NSC>([&](auto stc) {
+                    constexpr int st = decltype(stc)::value;
+                    {   // wait for this step's ring slot; the count: halo_ring_young (below the kernel)
+                        constexpr int NY = halo_ring_young<WCH, PFS, HI, ST0>(st, NSC, NS, !RAG);
+                        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(wr[st % PFS][0]), "+v"(wr[st % PFS][1]), "+v"(wr[st % PFS][2]), "+v"(wr[st % PFS][3]),
+                                                             "+v"(wr[st % PFS][4]) : "n"(NY));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const half_t* rsrc_w = wsrc_of(cc, st - 1 + PFS, NSC);      // step st reloads the slot of step st - 1
+                    const int toff = toff_of(st);
+#pragma unroll
+                    for (int k = 0; k < 2 * WCH; ++k) {                          // pairs of MFMAs on position fragments 0-3
+                        const int ci = k >> 1, p0 = (k & 1) * 2;
+                        acc[ci][p0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afA[p0], acc[ci][p0], 0, 0, 0);
+                        acc[ci][p0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afA[p0 + 1], acc[ci][p0 + 1], 0, 0, 0);
+                        if (k >= 2 && k < 6) afB[k - 2] = *(const h8_t*)(hb + ab_of(HA + k - 2, st) + toff);
+                        if constexpr (st >= 1) { if (k >= 5) wload1(wr[(st - 1) % PFS][k - 5], rsrc_w, k - 5); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (!RAG && st >= ST0 && st < ST0 + HI) { stage_piece(nbuf, cc + 1, st - ST0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int k = 0; k < 2 * WCH; ++k) {                          // ... on fragments 4-7, with the LDS reads of the next step's 0-3
+                        const int ci = k >> 1, p0 = (k & 1) * 2;
+                        acc[ci][HA + p0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afB[p0], acc[ci][HA + p0], 0, 0, 0);
+                        acc[ci][HA + p0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, wr[st % PFS][ci]), afB[p0 + 1], acc[ci][HA + p0 + 1], 0, 0, 0);
+                        if (k >= 2 && k < 6 && st + 1 < NSC) afA[k - 2] = *(const h8_t*)(hb + ab_of(k - 2, st + 1) + toff_of(st + 1));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                {   // the slot of the last step serves the next chunk
+                    const half_t* rsrc_w = wsrc_of(cc, NSC - 1 + PFS, NSC);
+#pragma unroll
+                    for (int ci = 0; ci < WCH; ++ci) wload1(wr[(NSC - 1) % PFS][ci], rsrc_w, ci);
+                }
+            };
+            const bool rag = RAGK && p.ragged && cc_hi == nck;
+            for (int cc = cc_lo; cc < cc_hi - (rag ? 1 : 0); ++cc) run_chunk_a(cc, std::false_type{});
+            if constexpr (RAGK) {
+                if (rag) run_chunk_a(cc_hi - 1, std::true_type{});
+            }
+            wait_vmcnt_le<0>();          // the ring's last (dropped) fetches: loads the compiler does not know of
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         u4_t wr[PFS][WCH];
         // In this fully unrolled body hipcc counts vmcnt / lgkmcnt exactly (the only conservative drain sits at the chunk
         // loop's back-edge, next to the barrier), so the weight fragments are ordinary loads here.
@@ -473,6 +642,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         for (int cc = cc_lo; cc < cc_hi - (rag ? 1 : 0); ++cc) { const unsigned char* hb = chunk_head(cc); run_chunk(cc, hb, std::false_type{}); }
         if constexpr (RAGK) {
             if (rag) { const unsigned char* hb = chunk_head(cc_hi - 1); run_chunk(cc_hi - 1, hb, std::true_type{}); }
+        }
         }
     } else {
         // This wave's K-step sequence: for every chunk cc, "fine" steps j = j0, j0+SKS, ... < ntaps*nhalf(cc) with
@@ -746,6 +916,21 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     // buffered ones - measured 3 % slower on the whole step: profiles/r02_notes.md)
     const bool db = nck > 1 && 2 * HV * VS <= (big || (WCH == 4 && PAD == 2) ? 128 : 64) * 1024 && HV * SLP <= 256 * HI;
     size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
+#ifndef CS_NO_ASMRING
+    constexpr bool asmr = WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8) && MODE == MODE_STD && !SK;      // see the kernel (ASMR)
+#else
+    constexpr bool asmr = false;
+#endif
+    ConvParams kp = p;
+    if (asmr && db) {
+        lds = (size_t)2 * HI * 4096;          // buffer stride of a whole number of DMA pieces
+        const long span = (long)(p.inD - 1) * p.in_sD + (long)((p.H - 1) >> p.up_shift) * p.in_sH + (long)((p.W - 1) >> p.up_shift) * p.in_sW + p.Cin + 32;
+        if (span >= (1L << 30) || p.cg > 0 || p.hilo || (1 << lgS) != BM) {
+            cs_set_error("conv_halo: the 256 x 160 tiles address one sample of the input through a buffer of less than 2^31 bytes (no grouped / split-precision input)");
+            return -1;
+        }
+        kp.in_sample_bytes = (unsigned)(span * 2);
+    }
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
@@ -759,7 +944,6 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     }
     if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1);
     hipError_t e;
-    ConvParams kp = p;
     {   // exact division of the workgroup index by the tile counts as one multiply-high each (u / d == umulhi(u, 2^32 / d + 1) while
         // u * d < 2^32; 0 encodes d == 1): four runtime integer divisions cost every workgroup about a hundred issue slots
         const unsigned long long umax = (unsigned long long)grid.x * grid.y;

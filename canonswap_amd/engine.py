@@ -48,13 +48,13 @@ class Engine:
             pass
 
     # ---------------------------------------------------------------- weights
-    def load_state_dicts(self, state_dicts: dict, fp8_weights: bool = False):
-        """Ingest the reference's six state-dicts (src/can_swap_e2e.py:87-100 key layout).  fp8_weights: every conv weight is
-        first quantised to e4m3 with a per-out-channel scale (BASELINE configs[4], pack.quantize_conv_weights_e4m3)."""
-        self.fp8_weights = bool(fp8_weights)
-        if fp8_weights:
-            state_dicts = pack.quantize_conv_weights_e4m3(state_dicts)
-        blobs = pack.build_blobs(state_dicts)
+    def load_state_dicts(self, state_dicts: dict):
+        """Ingest the reference's six state-dicts (src/can_swap_e2e.py:87-100 key layout)."""
+        self.load_blobs(pack.build_blobs(state_dicts))
+
+    def load_blobs(self, blobs: dict):
+        """Upload packed weight blobs (pack.build_blobs): the load-time transform runs once; N ranks of one node can share its result
+        (bench.py packs on rank 0 and hands the blobs over through /dev/shm)."""
         for name, arr in blobs.items():
             arr = np.ascontiguousarray(arr)
             _lib.check(self.lib.cs_upload(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.nbytes), f"cs_upload({name})")

@@ -374,41 +374,3 @@ def build_blobs(state_dicts: dict) -> dict:
     if "motion_extractor" in state_dicts:                      # optional
         _pack_M(out, _np_sd(state_dicts["motion_extractor"]))
     return out
-
-
-# ------------------------------------------------------------------------------------------------
-# fp8 conv weights (BASELINE configs[4]: "fp16 activations + fp8 conv weights")
-# ------------------------------------------------------------------------------------------------
-def round_e4m3(x):
-    """Round to the nearest OCP e4m3fn value (gfx950's fp8: 4 exponent bits, bias 7, 3 mantissa bits, max 448, subnormal
-    step 2^-9), ties to even, saturating."""
-    x = np.asarray(x, np.float64)
-    ax = np.abs(x)
-    e = np.floor(np.log2(np.maximum(ax, 2.0 ** -9)))
-    e = np.clip(e, -6, 8)
-    step = 2.0 ** (e - 3)
-    q = np.minimum(np.round(ax / step) * step, 448.0)
-    return np.sign(x) * q
-
-
-def quantize_conv_weights_e4m3(state_dicts: dict) -> dict:
-    """Weight-only fp8 quantisation of every convolution of the generator path: each output channel (row) of a conv weight
-    becomes scale[o] * q[o, ...] with q on the e4m3 grid and scale[o] = max|row| / 448 (per-out-channel scale, as configs[4]
-    asks).  The result is returned as ordinary state-dicts holding the de-quantised values, so the same loader and the same fp16
-    MFMA kernels run it: a row's e4m3 codes times one fp32 scale, rounded once more to fp16 (2^-11 against the 2^-4 steps of
-    e4m3).  gfx950 has no MFMA with fp16 x fp8 operands (the fp8 MFMAs take fp8 on both sides), so with fp16 activations the
-    weights are expanded to fp16 for the matrix pipe either way; what this mode delivers is the numerics of fp8 weights
-    (reported per module in DESIGN.md), not a higher MFMA rate.  Linear layers, norms and the motion extractor are left alone."""
-    out = {}
-    for m, sd in state_dicts.items():
-        new = type(sd)()
-        for k, v in sd.items():
-            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
-            if a.ndim >= 4 and (k.endswith(".weight") or k.endswith(".weight_orig")) and m != "motion_extractor":
-                rows = a.reshape(a.shape[0], -1).astype(np.float64)
-                scale = np.abs(rows).max(axis=1) / 448.0
-                scale[scale == 0] = 1.0
-                a = (round_e4m3(rows / scale[:, None]) * scale[:, None]).reshape(a.shape).astype(np.float32)
-            new[k] = a
-        out[m] = new
-    return out

@@ -1,8 +1,8 @@
 """CPU only: which fp16 rounding inside F (appearance_feature_extractor.py:38-48) costs the frame its PSNR - per conv, weights and conv inputs apart; the rest of
 the frame is the exact fp32 oracle.  This is the measurement behind the split-precision weights of F's three 2-D convs (engine.hip: wsplit_in).
-    python tests/emul_precision_F.py 63"""
+    python tests/diag/emul_precision_F.py 63"""
 import sys, time, torch, torch.nn.functional as F
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from canonswap_amd import synth
 from oracle import canonswap_ref as O
 torch.set_num_threads(16)

@@ -1,12 +1,12 @@
 """CPU only: which fp16 rounding inside R's twelve GroupNorm convs (util.py:528-544) costs the frame its PSNR - weights and conv inputs apart, the rest of
-the frame exact fp32.  Prices a two-pass (weights-only) split against the engine's three-pass one.   python tests/emul_precision_R.py 63"""
+the frame exact fp32.  Prices a two-pass (weights-only) split against the engine's three-pass one.   python tests/diag/emul_precision_R.py 63"""
 import os
 import sys
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from canonswap_amd import synth  # noqa: E402
 from oracle import canonswap_ref as O  # noqa: E402
 

@@ -1,8 +1,8 @@
 """CPU only: which fp16 rounding inside T (adaptive_modulate.py:128-193, 522-554) costs the frame its PSNR.  The oracle runs the whole frame in fp32 except for
 the roundings named per row (weights / conv inputs of the 14 blend convs and of the six ResBlock3d); the final image is compared with the exact one.
-    python tests/emul_precision_T.py 63"""
+    python tests/diag/emul_precision_T.py 63"""
 import sys, time, torch, torch.nn.functional as F
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from canonswap_amd import synth
 from oracle import canonswap_ref as O
 torch.set_num_threads(16)

@@ -1,11 +1,11 @@
 """GPU box: which stage's error costs the frame its PSNR.  The engine's stages are chained through the class API with the oracle's tensor substituted
-at one boundary at a time: PSNR of the final image when everything up to that boundary is exact.   python tests/psnr_attrib.py 63 3 19 23"""
+at one boundary at a time: PSNR of the final image when everything up to that boundary is exact.   python tests/diag/psnr_attrib.py 63 3 19 23"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from canonswap_amd import synth  # noqa: E402
 from canonswap_amd.can_swap_e2e import can_swapper  # noqa: E402

@@ -1,12 +1,12 @@
 """GPU box: PSNR of the engine's frames against the fp32 CPU oracle over many frames of bench.py's input pool (seed 1000) - the distribution behind
-the two-frame `psnr_db_min` of the bench line.   python tests/psnr_survey.py [first] [count] [stride]"""
+the two-frame `psnr_db_min` of the bench line.   python tests/diag/psnr_survey.py [first] [count] [stride]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from canonswap_amd import synth  # noqa: E402
 from canonswap_amd.can_swap_e2e import can_swapper  # noqa: E402

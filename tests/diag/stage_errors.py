@@ -1,11 +1,11 @@
 """GPU box: the measured error of every stage gate of tests/test_gpu_stages.py (relative L2 / PSNR against the fp32 CPU oracle), for three
-input seeds - the numbers the gates in that file are set from.   python tests/stage_errors.py > gpurun_out/stage_errors.txt"""
+input seeds - the numbers the gates in that file are set from.   python tests/diag/stage_errors.py > gpurun_out/stage_errors.txt"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from canonswap_amd import synth  # noqa: E402
 from canonswap_amd.can_swap_e2e import can_swapper  # noqa: E402

@@ -3,7 +3,7 @@
 Floating-point tolerance (BASELINE.json north_star): PSNR >= 50 dB on the 3x512x512 image in [0,1] against the
 fp32 CPU reference; intermediate feature tensors are checked by relative L2 error.  The engine computes with
 fp16 operands / fp32 accumulation (fp32 residual streams), so bit-exactness is not expected.  The stage gates sit about 3x above
-the errors measured on the GPU (tests/stage_errors.py -> profiles/r03_t_stage_errors.txt), not at a generic tolerance.
+the errors measured on the GPU (tests/diag/stage_errors.py -> profiles/r03_t_stage_errors.txt), not at a generic tolerance.
 """
 import numpy as np
 import pytest
@@ -41,7 +41,7 @@ def test_extract_feature_3d(swapper, case):
     args, _, ref = case
     f = swapper.extract_feature_3d(args["img"].cuda())
     assert f.shape == (2, 32, 16, 64, 64) and f.dtype == torch.float32
-    assert _rel(f, ref["f_s"]) < 1e-3                       # measured 3.95e-4 (tests/stage_errors.py, three seeds)
+    assert _rel(f, ref["f_s"]) < 1e-3                       # measured 3.95e-4 (tests/diag/stage_errors.py, three seeds)
 
 
 def test_warp(swapper, case):

@@ -155,3 +155,79 @@ def test_two_streams_on_four_ranks_gather_per_stream():
     assert [(s, r) for s, r, _ in got] == [(0, 0), (1, 2)]
     for s, _, frames in got:
         assert frames == [(10 * i + s + 1) % 256 for i in range(per_stream)]
+
+
+def test_equal_chunks():
+    """A rank's share runs as the fewest launches of at most the engine's batch, all of one size."""
+    assert parallel.equal_chunks(150, 64) == (50, [(0, 50), (50, 50), (100, 50)])
+    assert parallel.equal_chunks(64, 64) == (64, [(0, 64)])
+    assert parallel.equal_chunks(300, 64) == (60, [(t, 60) for t in range(0, 300, 60)])
+    size, chunks = parallel.equal_chunks(151, 64)
+    assert size == 51 and sum(n for _, n in chunks) == 151 and max(n for _, n in chunks) <= 64
+    assert parallel.equal_chunks(0, 64)[1] == []
+
+
+def _job_worker(rank, world, port, n_frames, max_batch, passes, q):
+    """BASELINE configs[3] shape (1200 frames over 8 ranks) with tiny frames: shard_range -> equal chunks -> ONE ChunkedFrameGather reused
+    over several passes; the leader gets every frame in order without a copy."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b = parallel.shard_range(n_frames, rank, world)
+        share = max(parallel.shard_range(n_frames, r, world)[1] - parallel.shard_range(n_frames, r, world)[0] for r in range(world))
+        size, _ = parallel.equal_chunks(share, max_batch)
+        chunks = [(t0, min(size, (b - a) - t0)) for t0 in range(0, b - a, size)]
+        g = parallel.ChunkedFrameGather(n_frames, size, frame_shape=(1, 2, 3))
+        buf0 = g.buf.data_ptr() if rank == 0 else None
+        res = []
+        for ps in range(passes):
+            g.reset()
+            for t0, n in chunks:
+                idx = torch.arange(a + t0, a + t0 + n)
+                fr = ((idx + 7 * ps) % 251).to(torch.uint8).view(-1, 1, 1, 1).expand(n, 1, 2, 3).contiguous()
+                g.push(fr)
+            out = g.finish()
+            if rank == 0:
+                assert out.shape[0] == n_frames
+                res.append((out[:, 0, 0, 0].tolist(), g.exact, out.data_ptr() == buf0))
+            else:
+                assert out is None
+        if rank == 0:
+            q.put((size, len(chunks), res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_1200_frames_on_8_ranks_equal_chunks_reused_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_frames, world, port, passes = 1200, 8, _free_port(), 2
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_frames, 64, passes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    size, nchunks, res = q.get(timeout=300)
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert (size, nchunks) == (50, 3)                         # 150 frames per rank: 3 launches of 50
+    for ps, (frames, exact, is_view) in enumerate(res):
+        assert exact and is_view                              # whole chunks on every rank: the receive buffer IS the video, no copy
+        assert frames == [(i + 7 * ps) % 251 for i in range(n_frames)]
+
+
+def test_ragged_job_on_3_ranks_reused_gather():
+    """100 frames over 3 ranks (34 + 33 + 33) at a 16-frame maximum: shares that are not whole chunks take the copying path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_frames, world, port = 100, 3, _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_frames, 16, 2, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    size, nchunks, res = q.get(timeout=300)
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert size == 12 and nchunks == 3
+    for ps, (frames, exact, _) in enumerate(res):
+        assert not exact
+        assert frames == [(i + 7 * ps) % 251 for i in range(n_frames)]

@@ -8,7 +8,7 @@ import sys
 def main(stats_csv, bench_json, steps):
     steps = int(steps)
     rows = list(csv.DictReader(open(stats_csv)))
-    conv = [r for r in rows if "conv_halo_kernel" in r["Name"] or "vol32_kernel" in r["Name"] or "vol32_fused_kernel" in r["Name"] or "t_mask_kernel" in r["Name"]]
+    conv = [r for r in rows if "conv_halo_kernel" in r["Name"] or "conv_wide_kernel" in r["Name"] or "vol32_kernel" in r["Name"] or "vol32_fused_kernel" in r["Name"] or "t_mask_kernel" in r["Name"]]
     warp = [r for r in rows if "grid_sample_kernel" in r["Name"] or "dm_softmax_warp_kernel" in r["Name"]]
     tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
     ctot = sum(float(r["TotalDurationNs"]) for r in conv) / 1e6

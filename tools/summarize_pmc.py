@@ -39,7 +39,7 @@ def main(root):
         print(f"\"{k}\",{nm[k]},{us:.1f},{fk:.1f},{fk * 2 / 1024:.1f},{wk:.1f},{busy / gui if gui else 0:.3f},{gui / (us * 1e3) if us else 0:.2f}")
 
 
-CONV_KERNELS = ("conv_halo_kernel", "vol32_kernel", "vol32_fused_kernel", "t_mask_kernel")
+CONV_KERNELS = ("conv_halo_kernel", "conv_wide_kernel", "vol32_kernel", "vol32_fused_kernel", "t_mask_kernel")
 WARP_KERNELS = ("dm_softmax_warp_kernel", "grid_sample_kernel")
 
 
