@@ -195,7 +195,10 @@ def _isa_check_ring(obj_dir: str, objdump: str, oname: str, name_re: str, expect
     for m in re.finditer(r"^[0-9a-f]+ <(" + name_re + r")>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         writer, waited, nmfma = {}, {}, 0
-        for l in body:
+        pending, nvm = [], 0          # ring loads in flight: (destination registers, VMEM ops issued before it); VMEM ops issued so far
+        mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+        lo, hi = (mf[0], mf[-1]) if mf else (0, 0)      # the in-flight check follows the K loop and what lies behind it up to the drain (straight-line there)
+        for li, l in enumerate(body):
             t = l.split("//")[0].strip()
             if not t:
                 continue
@@ -203,6 +206,26 @@ def _isa_check_ring(obj_dir: str, objdump: str, oname: str, name_re: str, expect
             if op.startswith("s_waitcnt") and "vmcnt" in t:
                 for r in waited:
                     waited[r] = True
+                n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                pending = [q for q in pending if nvm - q[1] - 1 < n]          # at most n VMEM ops are outstanding: the older ones have landed
+            # a load the compiler does not track writes its registers when the data lands, not where the instruction stands: nothing else may
+            # write them before a counted wait covers the load (the bug this guards against: a fetch whose result nobody reads looks dead to the
+            # register allocator, which hands its destination to another value)
+            if op.startswith(("s_cbranch", "s_branch", "s_endpgm")) or li < lo:
+                pending = []          # (the walk is textual: across a branch the issue order is not the text order)
+            if pending and not op.startswith(("s_", "global_store", "buffer_store", "ds_write", "scratch_store")):
+                mm0 = re.match(r"\S+\s+(v\[(\d+):(\d+)\]|v(\d+))", t)
+                if mm0 and not (op.startswith("buffer_load") and t.endswith("lds")):
+                    dst = set(range(int(mm0.group(2)), int(mm0.group(3)) + 1)) if mm0.group(2) else {int(mm0.group(4))}
+                    for regs, _ in pending:
+                        if regs & dst:
+                            raise RuntimeError(f"isa_check: {name}: `{t}` writes v{sorted(regs & dst)} while an untracked ring load into them is in flight")
+            if op.startswith(("global_load", "buffer_load", "global_store", "buffer_store", "scratch_load", "scratch_store", "global_atomic")):
+                if op.startswith("global_load_dwordx4") and li >= lo:
+                    q = re.match(r"\S+\s+v\[(\d+):(\d+)\]", t)
+                    if q:
+                        pending.append((set(range(int(q.group(1)), int(q.group(2)) + 1)), nvm))
+                nvm += 1
             if op.startswith("v_mfma"):
                 ops = re.findall(r"([av])\[(\d+):(\d+)\]", t)
                 if len(ops) < 4 or ops[1][0] != "v":

@@ -473,7 +473,11 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 halo_static_for<NSC>([&](auto stc) {
                     constexpr int st = decltype(stc)::value;
                     {   // wait for this step's ring slot; the count: halo_ring_young (below the kernel)
+#ifdef CS_ASMR_DEBUG0
+                        constexpr int NY = 0;
+#else
                         constexpr int NY = halo_ring_young<WCH, PFS, HI, ST0>(st, NSC, NS, !RAG);
+#endif
                         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(wr[st % PFS][0]), "+v"(wr[st % PFS][1]), "+v"(wr[st % PFS][2]), "+v"(wr[st % PFS][3]),
                                                              "+v"(wr[st % PFS][4]) : "n"(NY));
                     }
@@ -512,6 +516,11 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             }
             wait_vmcnt_le<0>();          // the ring's last (dropped) fetches: loads the compiler does not know of
             __builtin_amdgcn_sched_barrier(0);
+            // ... and whose results nobody reads: without a use BEHIND the drain hipcc treats their destination registers as free from the load
+            // on - in the straight-line ragged chunk it gave them to LDS fragments and addresses, which the landing data then overwrote
+#pragma unroll
+            for (int st = 0; st < PFS; ++st)
+                asm volatile("" :: "v"(wr[st][0]), "v"(wr[st][1]), "v"(wr[st][2]), "v"(wr[st][3]), "v"(wr[st][4]));
         } else {
         u4_t wr[PFS][WCH];
         // In this fully unrolled body hipcc counts vmcnt / lgkmcnt exactly (the only conservative drain sits at the chunk

@@ -299,6 +299,10 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
 
         wide_wait_vm<0>();      // the ring's last (dropped) fetches are loads the compiler does not know of: they must have landed before it reuses their registers
         __builtin_amdgcn_sched_barrier(0);
+        // (a use behind the drain: the destination registers of those loads stay reserved until the data has landed)
+#pragma unroll
+        for (int st = 0; st < W_PFS; ++st)
+            asm volatile("" :: "v"(wr[st][0]), "v"(wr[st][1]), "v"(wr[st][2]), "v"(wr[st][3]), "v"(wr[st][4]), "v"(wr[st][5]), "v"(wr[st][6]), "v"(wr[st][7]));
         WTL(6);
         // ---- epilogue (conv_epilogue.h): the tensor combination is a compile-time constant.  Stores are not waited for here.
         {
