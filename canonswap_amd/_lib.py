@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
     "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged", "cs_op_resblock3d", "cs_op_t_mask",
 ]
-ABI_VERSION = 2          # CS_ABI_VERSION of include/canonswap_hip.h
+ABI_VERSION = 3          # CS_ABI_VERSION of include/canonswap_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -275,7 +275,7 @@ class ConvDesc(C.Structure):
         ("hilo", C.c_int), ("stat_out", C.c_void_p),
         ("xf_kind", C.c_int), ("xf_y", C.c_void_p), ("xf_res", C.c_void_p), ("xf_out", C.c_void_p),
         ("xf_stats", C.c_void_p), ("xf_gamma", C.c_void_p), ("xf_beta", C.c_void_p), ("xf_slope", C.c_float),
-        ("ep_general", C.c_int),
+        ("ep_general", C.c_int), ("pool_hw", C.c_int),
     ]
 
 

@@ -111,6 +111,9 @@ struct ConvParams {
     float* kw_out;
     // tests / A/B (CANONSWAP_EP_GENERAL=1): run the general epilogue where the kernel also carries branch-free copies (conv_epilogue.h)
     int ep_general;
+    // conv_halo, 3-D tiles of 8 or 4 columns, fp16 out0 only: out0 = AvgPool(1,2,2) of act0(conv + bias) computed in the epilogue (DownBlock3d,
+    // util.py:185-190); out0's strides address the POOLED grid (h / 2, w / 2).  The average is taken over the fp32 values: one rounding.
+    int pool_hw;
     unsigned in_sample_bytes;   // conv_halo's 256 x 160 tiles (set by the launcher): bytes one sample of the input spans, the range of their buffer-addressed halo DMA
     int xf_kind;
     TDesc xf_y, xf_res, xf_out;

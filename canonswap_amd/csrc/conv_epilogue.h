@@ -255,6 +255,14 @@ _Pragma("unroll") \
 #ifndef EP_PIPE_V
 #define EP_PIPE_V 0
 #endif
+/* AvgPool(1,2,2) of out0 inside the epilogue (ConvParams::pool_hw; DownBlock3d, util.py:185-190): the four positions of a window are four
+   lanes of one 16-position block; a kernel that supports it names the two DPP row shifts (in lanes) that reach the w + 1 and h + 1
+   neighbours under its lane -> position map.  0: the kernel has no pooling epilogue. */
+#ifndef EP_POOL_WSH_V
+#define EP_POOL_WSH_V 0
+#define EP_POOL_HSH_V 0
+#endif
+#define EP_POOLB 128          /* EP_CODE bit: pooled out0 */
 /* one fetch round of the epilogue: residual / modulated tensor / per-position scale of the position blocks PG0 .. PG0 + EP_G - 1 -> register set BI */
 #define EP_FETCH_ROUND(PG0, BI) \
     if (EP_PF && !EP_EARLY && (ep_fetch || ep_has_ps)) { \
@@ -286,6 +294,8 @@ _Pragma("unroll") \
     constexpr int EPF = (EPCODE); \
     constexpr bool EPFAST = EPF >= 0; \
     constexpr bool EPALL = EPFAST && ((EPF >> 6) & 1) == 0;      /* every channel of the wave exists */ \
+    constexpr bool EP_POOL = EPFAST && ((EPF >> 7) & 1) != 0 && (EP_POOL_WSH_V) > 0;      /* out0 = AvgPool(1,2,2) of the activated values, on the pooled grid */ \
+    constexpr int EP_PS = EP_POOL ? 1 : 0; \
     const bool ep_has_res = EPFAST ? ((EPF & 3) != 0) : (p.res.p != nullptr); \
     const bool ep_res32 = EPFAST ? ((EPF & 3) == 2) : (p.res_f32 != 0); \
     const bool ep_has_o0 = EPFAST ? (((EPF >> 2) & 1) != 0) : (p.out0.p != nullptr); \
@@ -355,7 +365,9 @@ _Pragma("unroll") \
     const unsigned ep_lane_res = (unsigned)(ep_nb * (int)p.res.sN + (ep_tn1 ? 0 : ep_ln * (int)p.res.sN) + __mul24(ep_d0 + ep_ld, (int)p.res.sD) + \
                                             __mul24((ep_h0 + ep_lh) >> ep_rs, (int)p.res.sH) + __mul24((ep_w0 + ep_lw) >> ep_rs, (int)p.res.sW)); \
     const unsigned ep_lane_o0 = (unsigned)(ep_nb * (int)p.out0.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out0.sN) + __mul24(ep_d0 + ep_ld, (int)p.out0.sD) + \
-                                           __mul24(ep_h0 + ep_lh, (int)p.out0.sH) + __mul24(ep_w0 + ep_lw, (int)p.out0.sW)); \
+                                           __mul24((ep_h0 + ep_lh) >> EP_PS, (int)p.out0.sH) + __mul24((ep_w0 + ep_lw) >> EP_PS, (int)p.out0.sW)); \
+    /* pooled: the lanes whose position is the (even h, even w) corner of a window hold the window's sum and store it */ \
+    const bool ep_pool_lane = !EP_POOL || (lane & ((EP_POOL_WSH_V) | (EP_POOL_HSH_V))) == 0; \
     const unsigned ep_lane_o1 = (unsigned)(ep_nb * (int)p.out1.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out1.sN) + __mul24(ep_d0 + ep_ld, (int)p.out1.sD) + \
                                            __mul24(ep_h0 + ep_lh, (int)p.out1.sH) + __mul24(ep_w0 + ep_lw, (int)p.out1.sW)); \
     const unsigned ep_lane_ps = (unsigned)(((((ep_nb + ep_ln) * p.D + ep_d0 + ep_ld) * p.H + ep_h0 + ep_lh) * p.W + ep_w0 + ep_lw) * p.ps_stride); \
@@ -386,7 +398,7 @@ _Pragma("unroll") \
         float ps = 1.f; \
         if (ep_has_ps) ps = EP_PF ? ep_ps[g] : p.pixscale[ep_lane_ps + (unsigned)((((bn * p.D + bd) * p.H + bh) * p.W + bw) * p.ps_stride)]; \
         const unsigned xb = ep_lane_res + (unsigned)(bn * (int)p.res.sN + bd * (int)p.res.sD + (bh >> ep_rs) * (int)p.res.sH + (bw >> ep_rs) * (int)p.res.sW); \
-        const unsigned ob0 = ep_lane_o0 + (unsigned)(bn * (int)p.out0.sN + bd * (int)p.out0.sD + bh * (int)p.out0.sH + bw * (int)p.out0.sW); \
+        const unsigned ob0 = ep_lane_o0 + (unsigned)(bn * (int)p.out0.sN + bd * (int)p.out0.sD + (bh >> EP_PS) * (int)p.out0.sH + (bw >> EP_PS) * (int)p.out0.sW); \
         const unsigned ob1 = ep_lane_o1 + (unsigned)(bn * (int)p.out1.sN + bd * (int)p.out1.sD + bh * (int)p.out1.sH + bw * (int)p.out1.sW); \
         float ep_vh[4] = {0.f, 0.f, 0.f, 0.f}, ep_uh[4] = {0.f, 0.f, 0.f, 0.f};      /* first half of a channel pair, held for the joint store */ \
 _Pragma("unroll") \
@@ -456,8 +468,17 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \
+            if (EP_POOL) { /* (a + b) + (c + d) over the window, as DPP operands of the adds; x 0.25 */ \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) { \
+                    float t_ = v[r]; \
+                    t_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t_), 0x100 | (EP_POOL ? (EP_POOL_WSH_V) : 1), 0xf, 0xf, true)); \
+                    t_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t_), 0x100 | (EP_POOL ? (EP_POOL_HSH_V) : 1), 0xf, 0xf, true)); \
+                    v[r] = t_ * 0.25f; \
+                } \
+            } \
             const bool ep_hold = EP_PAIR != 0 && !ep_second(EP_PAIR, ci) && (EPALL || cb + 4 < p.Cout);      /* first half of a complete pair */ \
-            if (ep_has_o0 EP_STORE_COND) { \
+            if (ep_has_o0 && ep_pool_lane EP_STORE_COND) { \
                 if (ep_m0 && ep_hold) { \
 _Pragma("unroll") \
                     for (int r = 0; r < 4; ++r) ep_vh[r] = v[r]; \
@@ -507,7 +528,7 @@ _Pragma("unroll") \
 #define CONV_EPILOGUE() \
     { \
         int ep_code = -1; \
-        if constexpr (EP_FAST) { \
+        if constexpr (EP_FAST || (EP_POOL_WSH_V) > 0) { \
             constexpr int CST = (MODE == MODE_TBLEND || MODE == MODE_SPADE) ? 2 : 1; \
             const int ep_r0 = n0 + wch * WCH * 16; \
             const int ep_chi = (ep_r0 + WCH * 16) / CST;              /* one past the wave's last output channel */ \
@@ -516,7 +537,7 @@ _Pragma("unroll") \
                                (!p.res.p || p.res_f32 || EP_PAIR == 0 || ep_al8(p.res)) && \
                                (!p.out0.p || p.out0_f32 || EP_PAIR == 0 || ep_al8(p.out0)) && (!p.out1.p || EP_PAIR == 0 || ep_al8(p.out1)); \
             if (ep_ok) ep_code = EP_CODE(p.res.p ? (p.res_f32 ? 2 : 1) : 0, p.out0.p ? 1 : 0, p.out0_f32 ? 1 : 0, p.out1.p ? 1 : 0, p.pixscale ? 1 : 0) | \
-                                 (ep_call ? 0 : EP_RAGGED); \
+                                 (ep_call ? 0 : EP_RAGGED) | (p.pool_hw ? EP_POOLB : 0); \
         } \
         bool ep_done = false; \
         if constexpr (EP_FAST && MODE == MODE_SPADE) { \
@@ -524,6 +545,9 @@ _Pragma("unroll") \
         } \
         if constexpr (EP_FAST && (MODE == MODE_STD || MODE == MODE_STDSTAT)) { \
             if (ep_code == EP_CODE(0, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 0, 0, 0)); ep_done = true; } \
+        } \
+        if constexpr (MODE == MODE_STD && (EP_POOL_WSH_V) > 0) { \
+            if (ep_code == (EP_CODE(0, 1, 0, 0, 0) | EP_POOLB)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 0, 0, 0) | EP_POOLB); ep_done = true; } \
         } \
         if constexpr (EP_FAST && (MODE == MODE_STD || MODE == MODE_STDSTAT) && WCH != 5) { \
             if (ep_code == EP_CODE(1, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 1, 0, 0, 0)); ep_done = true; } \

@@ -23,6 +23,8 @@
 #ifdef CS_TIMELINE
 #define EP_TL(i) TL_STAMP(i)
 #endif
+#define EP_POOL_WSH_V EP_POOL_WSH_K      /* lane shifts of the pooling epilogue: per instantiation, from the lane -> position map (below) */
+#define EP_POOL_HSH_V EP_POOL_HSH_K
 #include "conv_epilogue.h"
 
 // Weight fragments are streamed with loads the compiler does not track (inline asm) and are waited for with an
@@ -109,7 +111,7 @@ template <int ST, int PAD> constexpr int halo_hi()
     return ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8) ? 13 : (ST == 12 ? 9 : 8));
 }
 // position (0..15 within its block) that lane l15 works on
-template <int ST, int PAD> __device__ __forceinline__ int halo_lane_pos(int l)
+template <int ST, int PAD> __host__ __device__ constexpr int halo_lane_pos(int l)
 {
 #ifdef CS_LDS_V1
     return l;
@@ -157,6 +159,13 @@ constexpr int halo_ring_young(int st, int L, int NP, bool dma_cur)
     return prime < carried ? prime : carried;
 }
 
+// lane shift (1, 2, 4, 8) that moves a lane to the neighbour whose position differs in bit `bit` of the 16-position block index
+template <int ST, int PAD> constexpr int halo_pool_shift(int bit)
+{
+    for (int b = 0; b < 4; ++b) if (halo_lane_pos<ST, PAD>(1 << b) == (1 << bit)) return 1 << b;
+    return 0;
+}
+
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 // Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
 // unrolled 128x128 tiles (<= 168 VGPRs, no scratch) -- for short-K convs a third workgroup hides the prologue / epilogue
@@ -171,6 +180,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr int SL = CK / 8;           // 16-byte slots per voxel
     constexpr int PAD = halo_pad<CK, WPX, WCH, WVP, ST, MODE>();
     constexpr int SLP = SL + PAD;        // ... plus the pad slot(s) (bank spreading; also fetched, from the zero page)
+    // pooling epilogue (ConvParams::pool_hw): 3-D static tiles of 8 or 4 columns - the w and h neighbours of a position lie in its 16-position block
+    constexpr bool EP_POOLK = ST != 0 && !SK && MODE == MODE_STD && WCH == 2 && SS::KD == 3 && SS::KH == 3 && SS::KW == 3 && (SS::LW == 3 || SS::LW == 2) && SS::LH >= 1;
+    constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : 0;
+    constexpr int EP_POOL_HSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(SS::LW) : 0;
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
     // halo pieces per thread whose source offsets are kept in registers (the big halos of the mask conv / 4x4x16 tiles too)
     constexpr int HI = halo_hi<ST, PAD>();
@@ -872,6 +885,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #endif
 }
 
+static inline int lgS_of(const ConvParams& p) { return p.lgTW + p.lgTH + p.lgTD; }
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool SK, int ST>
 static int launch_halo_st(const ConvParams& p, hipStream_t st)
 {
@@ -896,6 +910,16 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         return -1;
     }
     if (p.inD != p.D) { cs_set_error("conv_halo: depth-collapsing convs are not supported"); return -1; }
+    if (p.pool_hw) {
+        using SSL = StaticShape<ST>;
+        constexpr bool poolk = ST != 0 && !SK && MODE == MODE_STD && WCH == 2 && SSL::KD == 3 && SSL::KH == 3 && SSL::KW == 3 && (SSL::LW == 3 || SSL::LW == 2) && SSL::LH >= 1;
+        if (!poolk || p.res.p || p.out1.p || p.pixscale || p.stat_out || p.out0_f32 || !p.out0.p || p.sk_out || p.ep_general || (p.H & 1) || (p.W & 1) ||
+            p.Cout % 8 || p.Cout != p.Cout_pad || (1 << lgS_of(p)) != BM || ((unsigned long long)p.out0.p & 15ull) ||
+            ((p.out0.sN | p.out0.sD | p.out0.sH | p.out0.sW) & 7)) {
+            cs_set_error("conv_halo: pool_hw (AvgPool(1,2,2) in the epilogue) needs a static 3x3x3 tile of 8 or 4 columns with two channel fragments per wave, fp16 out0 only, every packed channel real");
+            return -1;
+        }
+    }
     if (p.kw_out) {
         constexpr bool kwsum = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && ST == 8;
         if (!kwsum || p.Cout_pad != 160 || p.lgTW != 1 || p.lgTH != 3 || p.lgTD != 4 || p.sk_out || p.W % 2 || p.nTN != p.N) {

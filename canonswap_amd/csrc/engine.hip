@@ -22,8 +22,8 @@ void cs_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* cs_last_error(void) { return g_err; }
-// 2 (round 4): cs_conv_desc grew (hilo, stat_out, xf_*, ep_general), cs_op_conv takes conv_halo / vol32 / conv_wide configurations only, the
-// packed weight blobs of F.down0 / down1 / second carry [W_hi | W_lo], W.occ49 exists.  _lib.load() refuses any other value.
+// 3 (round 4): cs_conv_desc grew (hilo, stat_out, xf_*, ep_general), cs_op_conv takes conv_halo / vol32 / conv_wide configurations only, the
+// packed weight blobs of F.down0 / down1 / second carry [W_hi | W_lo], W.occ49 exists; cs_conv_desc::pool_hw.  _lib.load() refuses any other value.
 extern "C" int cs_abi_version(void) { return CS_ABI_VERSION; }
 
 #define TRY(x) do { if ((x) != 0) return -1; } while (0)
@@ -563,8 +563,18 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_pre, FD, S, S, cout[i]);
         if (i == 0 && enc256()) c.hcfg = CFG_H_256x64;      // 64 channels at 64x64: 256-position tiles (0.65 -> 0.47 ms per 16 frames)
-        TRY(go(e, c, st));
         TDesc o = dhwc(e->dm_l[i + 1] + skip_off[i + 1], FD, S / 2, S / 2, lw[i + 1]);
+        // AvgPool3d((1,2,2)) of the block (util.py:189) inside the conv's epilogue: the average of the four fp32 values, rounded once, goes
+        // straight into the next level's concat buffer - no full-resolution tensor, no pooling launch (CANONSWAP_POOL_FOLD=0:
+        // the two-launch form, whose average is taken over fp16-rounded values).  Latency mode keeps the two launches (its split-K convs leave
+        // partial sums).
+        static const bool pool_fold = [] { const char* s = getenv("CANONSWAP_POOL_FOLD"); return !s || atoi(s) != 0; }();
+        if (pool_fold && !e->latency_mode) {
+            c.p.pool_hw = 1; c.p.out0 = o;
+            TRY(go(e, c, st));
+            continue;
+        }
+        TRY(go(e, c, st));
         TRY(e->run(1, st, [&] { return launch_avgpool(e->dm_pre, B, FD, S, S, cout[i], o, st); }, "avgpool"));
     }
     for (int i = 0; i < 5; ++i) {       // Decoder: UpBlock3d (util.py:142-147), nearest x(1,2,2) folded into addressing
@@ -1584,7 +1594,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     p.s2 = d->s2; p.t2 = d->t2; p.act1 = d->act1; p.slope1 = d->slope1;
     p.out1 = td(d->out1, d->out1_sN, d->out1_sD, d->out1_sH, d->out1_sW);
     p.stats = d->stats;
-    p.hilo = d->hilo; p.stat_out = d->stat_out;
+    p.hilo = d->hilo; p.stat_out = d->stat_out; p.pool_hw = d->pool_hw;
     if (d->xf_kind) {       // transform staging (vol32): the fp32 source volumes share out0's strides
         p.xf_kind = d->xf_kind;
         p.xf_y = td((void*)d->xf_y, d->out0_sN, d->out0_sD, d->out0_sH, d->out0_sW);

@@ -26,7 +26,7 @@ typedef struct cs_engine cs_engine;
 int cs_create(int device_id, int max_batch, cs_engine** out);   /* 1 <= max_batch <= 64; workspace ~0.35 GB per frame of batch */
 void cs_destroy(cs_engine* e);
 const char* cs_last_error(void);
-#define CS_ABI_VERSION 2       /* bumped whenever a struct of this header, an entry point's meaning or the weight blob format changes */
+#define CS_ABI_VERSION 3       /* bumped whenever a struct of this header, an entry point's meaning or the weight blob format changes */
 int cs_abi_version(void);
 /* Upload one packed weight blob (host pointer).  Names/layouts are produced by canonswap_amd/pack.py from
  * the reference's state-dict keys (BatchNorm / spectral norm folded, channels-last, fp16 MFMA order). */
@@ -151,6 +151,8 @@ typedef struct cs_conv_desc {
     const float* xf_stats; const float* xf_gamma; const float* xf_beta;
     float xf_slope;
     int ep_general;           /* tests / A/B: 1 forces the general epilogue where a kernel also carries branch-free copies of it (same bits) */
+    int pool_hw;              /* 1: out0 = AvgPool(1,2,2) of the activated conv output, computed in the epilogue; out0's strides address the pooled grid
+                                 (DownBlock3d, /root/reference/src/modules/util.py:185-190) */
 } cs_conv_desc;
 int cs_op_conv(const cs_conv_desc* d, void* stream);
 /* in place: re-pack the last 32-channel chunk of a packed conv weight [chunks * taps][Cout_pad][32] (Cin % 32 == 16) so that two

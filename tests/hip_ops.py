@@ -21,7 +21,7 @@ def strides_cl(t):
 
 def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0="none", slope0=0.0, res=None, res_shift=0,
          pixscale=None, ps_stride=1, out0=None, s2=None, t2=None, act1="none", slope1=0.0, out1=None, stats=None,
-         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0, xcd_map=None, ragged=False, hilo=False, stat_out=None, xf=None, ep_general=False):
+         mode=0, cfg=-1, up_shift=0, tile=(0, 0), out_dims=None, ck=0, xcd_map=None, ragged=False, hilo=False, stat_out=None, xf=None, ep_general=False, pool_hw=False):
     """x: [N, D, H, W, C] fp16 view (C contiguous). out0/out1/res: 5-D channels-last views. k = (KD, KH, KW)."""
     lib = _lib.load()
     d = _lib.ConvDesc()
@@ -60,6 +60,7 @@ def conv(x, wpacked, cout_pad, cout, k, *, cin=None, bias=None, bias2=None, act0
     d.ragged = int(ragged)
     d.hilo = int(hilo)
     d.ep_general = int(ep_general)
+    d.pool_hw = int(pool_hw)
     d.stat_out = 0 if stat_out is None else stat_out.data_ptr()
     if xf is not None:      # dict(kind, y, res, out, stats, gamma, beta, slope): fp32 volumes laid out like out0
         d.xf_kind = xf["kind"]

@@ -437,3 +437,24 @@ def test_conv_split_weights_use_fp16_subnormals():
     err = float((got - ref).norm() / ref.norm()); err_hi = float((ref_hi - ref).norm() / ref.norm())
     assert err_hi > 1e-4                     # what a flush of the subnormals would leave
     assert err < 2e-6, (err, err_hi)         # fp32 accumulation of 1152 products + 2^-18-relative weights
+
+
+@pytest.mark.parametrize("cfg,tile,N,Cin,Cout,H", [(10, (0, 0), 2, 64, 128, 16), (10, (4, 4), 2, 128, 128, 4), (11, (0, 0), 3, 64, 64, 8), (20, (8, 8), 2, 112, 64, 16),
+                                                    (10, (0, 0), 1, 96, 256, 32)])
+def test_conv_avgpool_in_the_epilogue(cfg, tile, N, Cin, Cout, H):
+    """DownBlock3d (util.py:185-190): conv3x3x3 + folded BN + ReLU + AvgPool3d((1,2,2)) as ONE launch (ConvParams::pool_hw): the average of
+    the four fp32 values goes straight into the next level's concat buffer, at a channel offset; neighbouring channels stay untouched."""
+    import hip_ops as ops
+    r = _rng(400 + cfg + H)
+    D, W = 16, H
+    x = _randn(r, N, Cin, D, H, W)
+    w = _randn(r, Cout, Cin, 3, 3, 3, scale=1.0 / np.sqrt(27 * Cin))
+    b = _randn(r, Cout, scale=0.1)
+    ref = F.avg_pool3d(F.relu(_ref_conv(x, w, b, 1)), (1, 2, 2))
+    xd = _to_cl(x).to(DEV)
+    wp = ops.packed_weight(w, Cout, DEV)
+    obuf = torch.full((N, D, H // 2, W // 2, Cout + 32), -5.0, dtype=torch.float16, device=DEV)
+    ops.conv(xd, wp, Cout, Cout, (3, 3, 3), bias=b.to(DEV), act0="relu", out0=obuf[..., 16:16 + Cout], out_dims=(N, D, H, W), cfg=cfg, tile=tile, pool_hw=True)
+    torch.cuda.synchronize()
+    assert ops.rel_err(_from_cl(obuf[..., 16:16 + Cout]), ref) < 2e-3
+    assert bool((obuf[..., :16] == -5.0).all()) and bool((obuf[..., 16 + Cout:] == -5.0).all())

@@ -50,6 +50,9 @@ def main():
     wps = torch.from_numpy(pack.pack_conv(w[:Cc], Cc)).to(DEV)
     res16 = res.half()
     so = torch.empty(B * 4 * 8 * 2 * Cc * 2, dtype=torch.float32, device=DEV)
+    actv = torch.relu(torch.randn(B, 1, 64, 64, 1536, device=DEV)).half()
+    wsp = torch.from_numpy(pack.pack_conv((r.standard_normal((2 * Cc, 128, 3, 3)) / np.sqrt(9 * 128)).astype(np.float32), 2 * Cc)).to(DEV)
+    stats = torch.stack([torch.zeros(B, Cc), torch.ones(B, Cc)], dim=2).contiguous().to(DEV)
     for cfg in [int(c) for c in a.cfgs.split(",")]:
         cases = {
             "T conv1 (blend, relu, fp16 out)": (1.0, lambda: ops.conv(x, wp, 2 * Cc, Cc, (1, 3, 3), bias=bias, pixscale=m4, ps_stride=4, act0="relu", out0=o16, mode=1, cfg=cfg)),
@@ -61,6 +64,9 @@ def main():
             "G c0 (fp16 out + statistics)": (0.5, lambda: ops.conv(x, wps, Cc, Cc, (1, 3, 3), bias=bias, out0=o16, stat_out=so, cfg=cfg)),
             "G c1 (fp16 res, fp16 out + statistics)": (0.5, lambda: ops.conv(x, wps, Cc, Cc, (1, 3, 3), bias=bias, res=res16, out0=o16, stat_out=so, cfg=cfg)),
         }
+        # SPADE gamma / beta conv of G_middle (util.py:295-302): 128 -> 2 x 512 on a 128-channel slice of the 1536-channel actv buffer
+        cases["G SPADE n0 (128 -> 2 x 512, IN-modulate x)"] = (0.25, lambda: ops.conv(actv[..., :128], wsp, 2 * Cc, Cc, (1, 3, 3), cin=128, bias=bias, bias2=bias,
+                                                                                       res=res16, stats=stats, act0="lrelu", slope0=0.2, out0=o16, mode=2, cfg=cfg))
         for name, (fscale, fn) in cases.items():
             if a.only and a.only not in name:
                 continue
