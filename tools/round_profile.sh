@@ -11,6 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_MFMA -o pmc --output-format csv -- python /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fixed-job > $OUT/pmc_MFMA.json 2> $OUT/pmc_MFMA.err
 cd /root/repo
+CANONSWAP_PROFILE_CSV=$OUT/layers_b64.csv python bench.py --no-cpu-baseline --no-fixed-job --steps 1 --warmup 2 > /dev/null 2>&1
+python tools/layer_table.py $OUT/layers_b64.csv > $OUT/families.txt 2>> $OUT/summarize.err
 python tools/summarize_pmc.py $OUT > $OUT/pmc_summary.csv 2> $OUT/summarize.err
 BATCH=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['config']['frames_per_launch_per_gpu'])")
 python tools/summarize_pmc.py $OUT $BATCH $OUT/hbm_traffic.json 2>> $OUT/summarize.err
