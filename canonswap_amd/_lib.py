@@ -176,7 +176,7 @@ def _isa_check_wide(obj_dir: str, objdump: str) -> dict:
     (src0) is a VGPR quadruple whose last writer is a `global_load_dwordx4` (never a copy of one: a copy made before the data landed would
     be stale) with a vmcnt wait between that load and the MFMA; conv_wide: 18 K-steps x 64 MFMAs per kernel."""
     seen = _isa_check_ring(obj_dir, objdump, "conv_wide.o", r"\S*conv_wide_kernel\S*", 18 * 64)
-    seen.update(_isa_check_ring(obj_dir, objdump, "conv_halo_g1.o", r"_Z16conv_halo_kernelILi32ELi8ELi5ELi2ELi2ELi0ELb1ELb0ELi[78]E\S*", None))
+    seen.update(_isa_check_ring(obj_dir, objdump, "conv_halo_g1.o", r"_Z16conv_halo_kernelILi32ELi8ELi5ELi2ELi2ELi0ELb1ELb0ELi[789]E\S*", None))
     return seen
 
 

@@ -82,6 +82,7 @@ GROUP_FN(1)     // mlp_shared phase convs (1x2x2 family, ahead of the generic 12
         if (mode == MODE_STDSTAT) return launch_halo_st<64, 8, 2, 2, 2, MODE_STDSTAT, false, 16>(p, st);
     }
     if (cfg == CFG_H_256x160 && mode == MODE_STD && ck == 32) {
+        if (p.KD == 7 && p.lgTW == 2) return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 9>(p, st);
         if (p.KD == 7) return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 8>(p, st);
         return launch_halo_cfg<32, 8, 5, 2, 2, MODE_STD, false, 7>(p, st);
     }

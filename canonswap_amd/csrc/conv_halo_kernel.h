@@ -70,6 +70,7 @@ template <> struct StaticShape<5> { static constexpr int KD = 3, KH = 3, KW = 3,
 template <> struct StaticShape<6> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 3; };
 template <> struct StaticShape<7> { static constexpr int KD = 3, KH = 3, KW = 3, LW = 3, LH = 3, LD = 2; };   // 256 positions: 8x8x4
 template <> struct StaticShape<8> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 1, LH = 3, LD = 4; };   // 256 positions: 2x8x16
+template <> struct StaticShape<9> { static constexpr int KD = 7, KH = 7, KW = 1, LW = 2, LH = 3, LD = 3; };   // 256 positions: 4x8x8 (the mask conv with the 4-column kw sum)
 template <> struct StaticShape<16> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 4, LD = 0; };   // 256 positions: 16x16 (2-D)
 template <> struct StaticShape<12> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 4; };
 template <> struct StaticShape<13> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 3, LH = 3, LD = 1; };
@@ -93,7 +94,7 @@ template <int CK, int WPX, int WCH, int WVP, int ST, int MODE> constexpr int hal
     return 1;
 #else
     if (CK == 64 && WCH == 4 && WPX == 8 && ST == 1) return 2;                       // 128x256 tiles (T, wide G / R convs): 2 workgroups per CU
-    if (CK == 32 && WCH == 5 && WPX == 8 && (ST == 7 || ST == 8)) return 2;           // 256x160 tiles: 1 workgroup per CU
+    if (CK == 32 && WCH == 5 && WPX == 8 && (ST == 7 || ST == 8 || ST == 9)) return 2;           // 256x160 tiles: 1 workgroup per CU
     if (CK == 64 && WCH == 2 && WPX == 8 && WVP == 2 && ST == 16) return 2;           // 256x64 2-D tiles: 2 workgroups per CU (2 x 52 KB)
     // SPADE gamma/beta convs (128x128, three workgroups per CU): the 64-channel image would not fit three times with two pad slots
     // (173 KB) and measured slower at two workgroups; with 32-channel chunks it does (104 KB) - the engine launches them that way
@@ -107,8 +108,8 @@ template <int CK, int WPX, int WCH, int WVP, int ST, int MODE> constexpr int hal
 // pieces per thread whose source offsets are kept in registers = ceil(halo voxels * slots per voxel / 256)
 template <int ST, int PAD> constexpr int halo_hi()
 {
-    if (PAD == 2) return ST == 3 ? 16 : ((ST == 7 || ST == 8) ? 15 : (ST == 16 ? 13 : 8));
-    return ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8) ? 13 : (ST == 12 ? 9 : 8));
+    if (PAD == 2) return ST == 3 ? 16 : (ST == 9 ? 19 : ((ST == 7 || ST == 8) ? 15 : (ST == 16 ? 13 : 8)));
+    return ST == 4 ? 18 : ((ST == 3 || ST == 7 || ST == 8 || ST == 9) ? 13 : (ST == 12 ? 9 : 8));
 }
 // position (0..15 within its block) that lane l15 works on
 template <int ST, int PAD> __host__ __device__ constexpr int halo_lane_pos(int l)
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         constexpr int NT = SS::KD * SS::KH * SS::KW, NS = NT * KH32;
         // kernels that carry the paired-tap body for a ragged last chunk (the 256-position tiles of the hourglass tail, the mask
         // conv and the first encoder block)
-        constexpr bool RAGK = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8) && MODE == MODE_STD;
+        constexpr bool RAGK = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD;
         // weight ring depth; the ring is re-primed at every chunk.  Three steps cover an L2 round trip where a step is 16-40 MFMAs; the
         // 16- and 32-channel tiles run 2-4 MFMAs per step and were bound by that latency (T's mask conv: 80 us for 134 MB): 8 steps
 #ifdef CS_PFS3
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #ifdef CS_NO_ASMRING
         constexpr bool ASMR = false;
 #else
-        constexpr bool ASMR = DB && WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8) && MODE == MODE_STD && PFS == 3;
+        constexpr bool ASMR = DB && WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD && PFS == 3;
 #endif
         if constexpr (ASMR) {
             static_assert(SK == false && KH32 == 1, "ASMR: 32-channel chunks");
@@ -768,7 +769,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // sigmoid / GELU epilogues exist in: the pixel-shuffle kernel (conv_img), the 16-channel tiles (T's mask conv), the 1x1 kernels
     // (the motion extractor's linear layers) and the dynamic-shape fallbacks (small maps of the same layers)
     constexpr bool EP_HEAVY = (MODE == MODE_PIXSHUF) || (WCH == 1) || (ST == 15) || (ST == 0);
-    constexpr bool KWSUM = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && ST == 8;      // the kw-split mask conv (ConvParams::kw_out)
+    constexpr bool KWSUM = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && (ST == 8 || ST == 9);      // the kw-split mask conv (ConvParams::kw_out)
     TL_STAMP(3);
     if constexpr (!SK) {
         if (p.sk_out) {      // split-K: this workgroup's partial sums, fp32, [split][position][channel]; finished by splitk_finish_kernel
@@ -791,7 +792,53 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             // depth slice d = wpx * 8 + pi with l15p = (h << 1) | w'.  Per depth slice the two channel waves of a position half lay their
             // 160 channels into LDS ([16 positions][160] fp32), then its 128 threads add, for each of the 8 output columns j (w0 - 3 + j)
             // the tile touches, P[w' = 0][kw = 6 - j] + P[w' = 1][kw = 7 - j] and store 8 x 22 logits per (d, h) - one 704-byte run.
-            if constexpr (KWSUM) {
+            if constexpr (KWSUM && ST == 9) {
+                // Tile 4 (w) x 8 (h) x 8 (d): a 16-position block is 4 columns x 4 rows of one depth slice (l15p = (h & 3) << 2 | w'), block pi of wave
+                // wpx = (depth slice wpx * 4 + pi / 2, row half pi & 1).  The tile's 4 columns reach the 10 output columns j = w0 - 3 + j; column j
+                // sums P[w'][kw = w' + 6 - j] over the w' with 0 <= kw <= 6 (1 to 4 terms, w' ascending: a fixed order).  Per block: both channel
+                // waves of the position half lay 16 x 160 floats into LDS, its 128 threads finish 4 rows x 10 x 22 logits = 220 float4 and store
+                // them as one 880-byte run per (d, h): kw_out[((n D + d) H + h) (W / 4) + tile][j][22] - 10 vectors per 4 voxels instead of 8 per 2.
+                __syncthreads();                               // every wave has left the halo: the LDS is free
+                constexpr int ZERO = 16 * 160;
+                float* buf = (float*)smem + wpx * (16 * 160 + 4);
+                const int th128 = wch * 64 + lane;
+                if (th128 == 0) buf[ZERO] = 0.f;
+                int offT[2][4][4]; int goff[2]; bool on[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int fi = q * 128 + th128;            // float4 index, 220 per block
+                    on[q] = fi < 220;
+                    const int fic = on[q] ? fi : 0;
+                    goff[q] = (fic / 55) * (p.nTW * 220) + (fic % 55) * 4;      // row h' of the block (55 float4 per row), position inside the row's 220 floats
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idx = (fic % 55) * 4 + e, c = idx % 22, j = idx / 22, h = fic / 55;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {          // term t: column w' = t
+                            const int kw = t + 6 - j;
+                            offT[q][e][t] = (kw >= 0 && kw <= 6) ? ((h << 2) | t) * 160 + kw * 22 + c : ZERO;
+                        }
+                    }
+                }
+                const long gslice = (long)p.H * p.nTW * 220;  // one depth slice further
+                float* const gbase = p.kw_out + ((((long)tn * p.D + (td << lgTD) + wpx * 4) * p.H + (th << lgTH)) * p.nTW + tw) * 220;
+#pragma unroll
+                for (int pi = 0; pi < WPX; ++pi) {
+#pragma unroll
+                    for (int ci = 0; ci < WCH; ++ci) *(f4_t*)(buf + l15p * 160 + wch * (WCH * 16) + ci * 16 + l4 * 4) = acc[ci][pi];
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (on[q]) {
+                            f4_t v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((buf[offT[q][e][0]] + buf[offT[q][e][1]]) + buf[offT[q][e][2]]) + buf[offT[q][e][3]];
+                            *(f4_t*)(gbase + (pi >> 1) * gslice + (long)(pi & 1) * 4 * (p.nTW * 220) + goff[q]) = v;
+                        }
+                    }
+                    __syncthreads();
+                }
+            } else if constexpr (KWSUM) {
                 __syncthreads();                               // every wave has left the halo: the LDS is free
                 constexpr int ZERO = 16 * 160;                 // a zero float behind the image of a position half: the missing term at j = 0 / 7
                 float* buf = (float*)smem + wpx * (16 * 160 + 4);
@@ -921,9 +968,10 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         }
     }
     if (p.kw_out) {
-        constexpr bool kwsum = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && ST == 8;
-        if (!kwsum || p.Cout_pad != 160 || p.lgTW != 1 || p.lgTH != 3 || p.lgTD != 4 || p.sk_out || p.W % 2 || p.nTN != p.N) {
-            cs_set_error("conv_halo: kw_out is the mask conv's epilogue (7x7x1 taps, 160 packed channels, 2x8x16 tiles of one sample)");
+        constexpr bool kwsum = !SK && MODE == MODE_STD && WCH == 5 && WPX == 8 && WVP == 2 && (ST == 8 || ST == 9);
+        if (!kwsum || p.Cout_pad != 160 || p.lgTH != 3 || !((p.lgTW == 1 && p.lgTD == 4) || (p.lgTW == 2 && p.lgTD == 3)) || p.sk_out || p.W % (1 << p.lgTW) ||
+            p.nTN != p.N) {
+            cs_set_error("conv_halo: kw_out is the mask conv's epilogue (7x7x1 taps, 160 packed channels, 2x8x16 or 4x8x8 tiles of one sample)");
             return -1;
         }
     }
@@ -932,7 +980,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if (MODE == MODE_SPADE && (1 << lgS) != BM) { cs_set_error("conv_halo: SPADE launches must tile within one sample"); return -1; }
     if (MODE == MODE_SPADE && p.res_f32) { cs_set_error("conv_halo: the tensor a SPADE launch modulates is fp16"); return -1; }
     if (p.ragged) {
-        constexpr bool ragk = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8) && MODE == MODE_STD;
+        constexpr bool ragk = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD;
         if (!ragk || SK || p.Cin % 32 != 16 || p.sk_out || p.hilo || p.cg > 0) {
             cs_set_error("conv_halo: paired-tap weights (ragged) need the 256-position 32-channel static kernels and Cin %% 32 == 16");
             return -1;
@@ -950,7 +998,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     const bool db = nck > 1 && 2 * HV * VS <= (big || (WCH == 4 && PAD == 2) ? 128 : 64) * 1024 && HV * SLP <= 256 * HI;
     size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
 #ifndef CS_NO_ASMRING
-    constexpr bool asmr = WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8) && MODE == MODE_STD && !SK;      // see the kernel (ASMR)
+    constexpr bool asmr = WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD && !SK;      // see the kernel (ASMR)
 #else
     constexpr bool asmr = false;
 #endif

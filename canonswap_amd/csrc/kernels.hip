@@ -247,6 +247,22 @@ __device__ __forceinline__ void dm_logits(float (&l)[22], const float* __restric
 {
 #pragma unroll
     for (int k = 0; k < 22; ++k) l[k] = bias[k];
+    if (compact == 2) {
+        // the 4-column tiles' sums: part[((n D + d) H + y) * (W / 4) + T][j][22], j <-> output column 4 T - 3 + j (10 per tile); x lies in the
+        // reach of (up to) three tiles, T ascending: a fixed order
+        const long row = (v - x) / 4 * 220;
+        const int T0 = (x + 1) / 4 - 1;                      // = ceil((x - 6) / 4): the smallest T with 4 T + 6 >= x
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int T = T0 + dt, j = x - 4 * T + 3;
+            if ((unsigned)T < (unsigned)(W >> 2) && (unsigned)j < 10u) {
+                const float2* src = (const float2*)(part + row + (long)T * 220 + j * 22);
+#pragma unroll
+                for (int k = 0; k < 11; ++k) { const float2 q = src[k]; l[2 * k] += q.x; l[2 * k + 1] += q.y; }
+            }
+        }
+        return;
+    }
     if (compact) {
         const long row = (v - x) / 2 * 176;                  // first tile of this (n, d, y) row: (v - x) is the row's first voxel, W / 2 tiles x 176
         const int T0 = (x >> 1) - 2 + (x & 1);
@@ -316,7 +332,7 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
 int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
                       int N, int D, int H, int W, hipStream_t st, int compact)
 {
-    if (compact && (W & 1)) { cs_set_error("dm_softmax: the compact partial layout needs an even width"); return -1; }
+    if ((compact == 1 && (W & 1)) || (compact == 2 && (W & 3))) { cs_set_error("dm_softmax: the compact partial layouts need a width that is a multiple of the tile's columns"); return -1; }
     hipLaunchKernelGGL(dm_softmax_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, part, bias, kp_d, kp_s,
                        deform, mask_out, N, D, H, W, compact);
     LAUNCH_CHECK("dm_softmax");
