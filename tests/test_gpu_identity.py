@@ -139,3 +139,18 @@ def test_reloading_weights_refreshes_every_identity_slot(state_dicts_np, feats):
     live.load_state_dicts(sd_a)
     back = live.swap_module(f.flip(0).contiguous(), ids.flip(0).contiguous().cuda())
     assert torch.equal(back[1], out_a[0]) and torch.equal(back[0], out_a[1])
+
+
+def test_mixed_identities_on_the_persistent_wide_kernel(state_dicts, feats):
+    """At 8 samples and more T's blend convs run on conv_wide (persistent 256 x 256 tiles), which picks the weight set per item from the
+    per-sample slot vector.  Three identities mixed over 12 samples: every sample equals the same sample run alone with its identity
+    (one sample per call runs on conv_halo - the two kernels give the same bits)."""
+    from canonswap_amd.can_swap_e2e import can_swapper
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=12)
+    f = torch.cat([feats, feats.flip(0), feats * 0.5], dim=0).contiguous()        # 12 distinct volumes
+    seeds = [7, 8, 9, 8, 7, 7, 9, 8, 9, 9, 7, 8]
+    ids = _ids(*seeds)
+    got = sw.swap_module(f.cuda(), ids.cuda())
+    for b in (0, 1, 2, 5, 6, 11):
+        alone = sw.swap_module(f[b:b + 1].cuda(), ids[b:b + 1].cuda())
+        assert torch.equal(got[b], alone[0]), b
