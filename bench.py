@@ -368,8 +368,8 @@ def main():
                          "conv_ms_per_step": round(prof["conv_ms"] / K, 3),
                          "end_to_end_frac": round(ALGO_GFLOP_PER_FRAME * 1e9 * fps / world / (PEAK_TFLOPS_F16 * 1e12), 4)},
             # the HBM-bound row of the path: softmax -> deformation -> trilinear feature warp in one kernel (dm_softmax_warp_kernel)
-            "warp_roofline": {"bound": "hbm", "kernel": "dm_softmax_warp_kernel (mask softmax + deformation + feature warp; the logits arrive as 8 x 22 "
-                                                        "fp32 partial sums per two voxels from the mask conv's in-tile kw sum: 4x the algorithmic 5.77 MB)",
+            "warp_roofline": {"bound": "hbm", "kernel": "dm_softmax_warp_kernel (mask softmax + deformation + feature warp; the logits arrive as 10 x 22 "
+                                                        "fp32 partial sums per four voxels from the mask conv's in-tile kw sum: 2.5x the algorithmic 5.77 MB)",
                               "algorithmic_mb_per_frame": round(WARP_BYTES_PER_FRAME / 1e6, 2),
                               "achieved": round(WARP_BYTES_PER_FRAME * plan.n_local * K / (prof["warp_ms"] / 1e3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s",
