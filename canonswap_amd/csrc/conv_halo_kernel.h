@@ -220,16 +220,46 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr int EP_PAIR = ep_pair_of(MODE, WCH);     // weight-row permutation / joint stores of channel pairs (conv_epilogue.h)
 #endif
 
+    // ---- persistent mode (the ASMR kernels, ConvParams::persist_total > 0; see the ASMR block below): the workgroup walks a list of tiles.
+    // XCD x owns persist_total / 8 consecutive entries of the launch order (as in xcd_map 2), its workgroups take them round robin, so the
+    // tiles in flight in an XCD are neighbours; the state below lives across tiles: the weight ring (the last steps of a tile fetch the
+    // first steps of the next one: the weights are the same), the staging offsets / buffer of the tile being staged (the next tile's first
+    // chunk is staged under the last chunk's MFMAs), the LDS buffer parity.
+#ifdef CS_NO_ASMRING
+    constexpr bool ASMRK = false;
+#else
+    constexpr bool ASMRK = DB && !SK && CK == 32 && WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD;
+#endif
+    u4_t wr_p[ASMRK ? 3 : 1][ASMRK ? WCH : 1];
+    unsigned poffb[ASMRK ? HI : 1];
+    __amdgpu_buffer_rsrc_t rsrc_p;
+    int gbuf = 0;
+    bool staged = false;                          // this tile's first chunk and ring were staged by the previous tile
+    const bool persist = ASMRK && p.persist_total > 0;
+    int p_base = 0, p_cnt = 0, p_j = 0, p_i = 0, p_per = 1;
+    if (persist) {
+        const int total = p.persist_total, G = (int)gridDim.x;
+        const int xcd = blockIdx.x & 7, q = total >> 3, r = total & 7;
+        p_i = blockIdx.x >> 3; p_per = G >> 3;
+        p_base = xcd * q + (xcd < r ? xcd : r); p_cnt = q + (xcd < r ? 1 : 0);
+        if (p_i >= p_cnt) return;
+    }
+    for (;;) {
     // position tile / channel block of this workgroup (ConvParams::xcd_map)
     int tile_lin = blockIdx.x, cblk = blockIdx.y;
-    if (p.xcd_map != 0) {
-        const int flat = p.xcd_map == 2;
+    const bool has_next = persist && p_i + p_per * (p_j + 1) < p_cnt;
+    auto u_to_tile = [&](int u, int& tl_, int& cb_) {
         const int ncb = p.Cout_pad / BN;
+        tl_ = (int)mdiv((unsigned)u, p.mg_ncb); cb_ = u - tl_ * ncb;
+    };
+    if (persist) u_to_tile(p_base + p_i + p_per * p_j, tile_lin, cblk);
+    else if (p.xcd_map != 0) {
+        const int flat = p.xcd_map == 2;
         const int total = (int)gridDim.x;                               // mode 1: tiles; mode 2: tiles x channel blocks
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
         const int q = total >> 3, r = total & 7;
         const int u = xcd * q + (xcd < r ? xcd : r) + i;                // bijection: XCD x owns q + (x < r) consecutive entries
-        if (flat) { tile_lin = (int)mdiv((unsigned)u, p.mg_ncb); cblk = u - tile_lin * ncb; }
+        if (flat) u_to_tile(u, tile_lin, cblk);
         else tile_lin = u;
     }
     // (mg_*: multiply-high constants of launch_halo_st for these divisions)
@@ -411,31 +441,38 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             constexpr int ST0 = 1;                   // K-steps ST0 .. ST0 + HI - 1 of a chunk each issue one DMA piece of the next chunk
             constexpr unsigned OOB = 0x80000000u;    // byte offset outside the buffer (the launcher keeps a sample below 2^31 bytes): the lane reads zeros
             // per-sample buffer: pad slots, voxels outside the volume, lanes beyond the image and channels beyond Cin carry OOB
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)nb * p.in_sN), 0, (int)p.in_sample_bytes, 0x00020000);
-            unsigned poffb[HI];
+            static_assert(ASMRK, "the kernel-level and the block-level conditions of ASMR agree");
+            auto (&wr) = wr_p;
+            // staging offsets of a tile (set_stage: this tile at the first tile of the workgroup, the NEXT tile at the head of every last chunk)
+            auto set_stage = [&](int n_, int d0_, int h0_, int w0_) {
+                rsrc_p = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (long)n_ * p.in_sN), 0, (int)p.in_sample_bytes, 0x00020000);
+                int tid_o = tid;
+                asm volatile("" : "+v"(tid_o));              // (opaque: the tile-invariant part of this addressing is not to be hoisted out of the tile loop)
 #pragma unroll
-            for (int j = 0; j < HI; ++j) {
-                const int q = tid + 256 * j;
-                const int hv = q / SLP, sl = q % SLP;
-                const int hw = hv % HW; int r = hv / HW;
-                const int hh = r % HH; r /= HH;
-                const int id = d0 + r - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW;
-                const bool inb = q < nitems && sl < SL && r < HD && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                poffb[j] = inb ? (unsigned)(__mul24(id, isD) + __mul24(ih >> p.up_shift, isH) + __mul24(iw >> p.up_shift, isW) + sl * 8) * 2u : OOB;
-            }
-            // piece j of chunk cn (cn >= cc_hi: nothing to stage, every lane out of range)
+                for (int j = 0; j < HI; ++j) {
+                    const int q = tid_o + 256 * j;
+                    const int hv = q / SLP, sl = q % SLP;
+                    const int hw = hv % HW; int r = hv / HW;
+                    const int hh = r % HH; r /= HH;
+                    const int id = d0_ + r - p.PD, ih = h0_ + hh - p.PH, iw = w0_ + hw - p.PW;
+                    const bool inb = q < nitems && sl < SL && r < HD && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    poffb[j] = inb ? (unsigned)(__mul24(id, isD) + __mul24(ih >> p.up_shift, isH) + __mul24(iw >> p.up_shift, isW) + sl * 8) * 2u : OOB;
+                }
+            };
+            // piece j of chunk cn of the tile the staging offsets belong to; cn >= cc_hi: the first chunk of the NEXT tile (the offsets were
+            // switched at the head of this tile's last chunk) - or, behind the workgroup's last tile, nothing (every lane out of range)
             auto stage_piece = [&](int buf, int cn, int j) {
-                const int c0 = cn * CK;
-                const int climit = cn < cc_hi ? p.Cin - c0 : 0;                  // channels of that chunk that exist
+                const bool nxt = cn >= cc_hi;
+                const int c0 = (nxt ? cc_lo : cn) * CK;
+                const int climit = (nxt && !has_next) ? 0 : p.Cin - c0;          // channels of that chunk that exist
                 const unsigned off = (((tid + 256 * j) % SLP) * 8 < climit) ? poffb[j] : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + (size_t)buf * HSTRIDE + (size_t)(256 * j + wave * 64) * 16),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_p, (__attribute__((address_space(3))) void*)(smem + (size_t)buf * HSTRIDE + (size_t)(256 * j + wave * 64) * 16),
                                                          16, (int)off, c0 * 2, 0, 0);
             };
-            u4_t wr[PFS][WCH];
             auto wsrc_of = [&](int cc, int st, int nsc) -> const half_t* {       // st may run past the chunk (the carried fetches)
                 int c2 = cc, s2 = st;
                 if (st >= nsc) { c2 = cc + 1; s2 = (nsc % PFS == 0) ? st - nsc : (st - PFS) % PFS; }      // the slot a step frees serves that step of the next chunk
-                const int ccl = c2 < nck ? c2 : nck - 1;                         // behind the last chunk the fetches repeat and are dropped
+                const int ccl = c2 < cc_hi ? c2 : cc_lo;                         // behind a tile's last chunk: the next tile's first chunk (the same weights; dropped behind the last tile)
                 return wlane + (long)(ccl * NT + s2) * wstep;
             };
             auto wload1 = [&](u4_t& dst, const half_t* src, int ci) {            // ci: compile-time after unrolling; EP_PAIR == 0 here: rows ci * 16
@@ -447,14 +484,21 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             };
             static_assert(EP_PAIR == 0, "ASMR: plain weight row order");
             TL_STAMP(1);
+            // (the 4-column mask tile, 19 staging offsets and the kw-sum epilogue: the ring does not stay live across the epilogue - that spilled the
+            // epilogue's tables, and every scratch reload is a full drain of the in-order memory queue, output stores included - but is primed again)
+            constexpr bool CARRY = ST != 9;
+            if (!staged) {                                   // the workgroup's first tile: staging burst
+                set_stage(nb, d0, h0, w0);
 #pragma unroll
-            for (int j = 0; j < HI; ++j) stage_piece(0, cc_lo, j);
+                for (int j = 0; j < HI; ++j) stage_piece(gbuf, cc_lo, j);
+            }
+            if (!staged || !CARRY) {                         // ring prime
 #pragma unroll
-            for (int st = 0; st < PFS; ++st)
+                for (int st = 0; st < PFS; ++st)
 #pragma unroll
-                for (int ci = 0; ci < WCH; ++ci) wload1(wr[st][ci], wsrc_of(cc_lo, st, NS), ci);
+                    for (int ci = 0; ci < WCH; ++ci) wload1(wr[st][ci], wsrc_of(cc_lo, st, NS), ci);
+            }
             TL_STAMP(2);
-            int gbuf = 0;
             auto run_chunk_a = [&](int cc, auto rag_t) {
                 constexpr bool RAG = decltype(rag_t)::value;
                 // head: this chunk's halo has landed - this wave's pieces by the counted wait (the PFS * WCH ring fetches are younger), everyone's by
@@ -465,6 +509,15 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 const unsigned char* hb = smem + (size_t)gbuf * HSTRIDE;
                 const int nbuf = gbuf ^ 1;
                 gbuf ^= 1;
+                if (cc + 1 == cc_hi && has_next) {           // the last chunk: from here on the staging offsets are the next tile's
+                    int ntl, ncb_, t2 = 0, q2;
+                    u_to_tile(p_base + p_i + p_per * (p_j + 1), ntl, ncb_);
+                    t2 = ntl;
+                    q2 = (int)mdiv((unsigned)t2, p.mg_tw); const int tw2 = t2 - q2 * p.nTW; t2 = q2;
+                    q2 = (int)mdiv((unsigned)t2, p.mg_th); const int th2 = t2 - q2 * p.nTH; t2 = q2;
+                    q2 = (int)mdiv((unsigned)t2, p.mg_td); const int td2 = t2 - q2 * p.nTD; t2 = q2;
+                    set_stage(t2 * TN, td2 << lgTD, th2 << lgTH, tw2 << lgTW);
+                }
                 constexpr int HA = WPX / 2;
                 constexpr int PK = SS::KW > 1 ? SS::KW : SS::KH, SPR = PK / 2 + PK % 2;
                 constexpr int NSC = RAG ? (NT / PK) * SPR : NS;
@@ -490,7 +543,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #ifdef CS_ASMR_DEBUG0
                         constexpr int NY = 0;
 #else
-                        constexpr int NY = halo_ring_young<WCH, PFS, HI, ST0>(st, NSC, NS, !RAG);
+                        constexpr int NY = halo_ring_young<WCH, PFS, HI, ST0>(st, NSC, NS, true);
 #endif
                         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(wr[st % PFS][0]), "+v"(wr[st % PFS][1]), "+v"(wr[st % PFS][2]), "+v"(wr[st % PFS][3]),
                                                              "+v"(wr[st % PFS][4]) : "n"(NY));
@@ -507,7 +560,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                         if constexpr (st >= 1) { if (k >= 5) wload1(wr[(st - 1) % PFS][k - 5], rsrc_w, k - 5); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (!RAG && st >= ST0 && st < ST0 + HI) { stage_piece(nbuf, cc + 1, st - ST0); __builtin_amdgcn_sched_barrier(0); }
+                    if (st >= ST0 && st < ST0 + HI) { stage_piece(nbuf, cc + 1, st - ST0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                     for (int k = 0; k < 2 * WCH; ++k) {                          // ... on fragments 4-7, with the LDS reads of the next step's 0-3
                         const int ci = k >> 1, p0 = (k & 1) * 2;
@@ -528,10 +581,14 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             if constexpr (RAGK) {
                 if (rag) run_chunk_a(cc_hi - 1, std::true_type{});
             }
-            wait_vmcnt_le<0>();          // the ring's last (dropped) fetches: loads the compiler does not know of
-            __builtin_amdgcn_sched_barrier(0);
+            staged = has_next;
+            if (!has_next || !CARRY) {
+                wait_vmcnt_le<0>();      // the ring's last (dropped) fetches: loads the compiler does not know of
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ... and whose results nobody reads: without a use BEHIND the drain hipcc treats their destination registers as free from the load
-            // on - in the straight-line ragged chunk it gave them to LDS fragments and addresses, which the landing data then overwrote
+            // on - in the straight-line ragged chunk it gave them to LDS fragments and addresses, which the landing data then overwrote.  (With a
+            // next tile the ring is live across the epilogue: its fetches are the next tile's first steps.)
 #pragma unroll
             for (int st = 0; st < PFS; ++st)
                 asm volatile("" :: "v"(wr[st][0]), "v"(wr[st][1]), "v"(wr[st][2]), "v"(wr[st][3]), "v"(wr[st][4]));
@@ -800,7 +857,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 // them as one 880-byte run per (d, h): kw_out[((n D + d) H + h) (W / 4) + tile][j][22] - 10 vectors per 4 voxels instead of 8 per 2.
                 __syncthreads();                               // every wave has left the halo: the LDS is free
                 constexpr int ZERO = 16 * 160;
-                float* buf = (float*)smem + wpx * (16 * 160 + 4);
+                float* buf = (float*)(smem + (ASMRK ? (size_t)(gbuf ^ 1) * (HI * 4096) : 0)) + wpx * (16 * 160 + 4);      // (ASMR: the buffer the last chunk read)
                 const int th128 = wch * 64 + lane;
                 if (th128 == 0) buf[ZERO] = 0.f;
                 int offT[2][4][4]; int goff[2]; bool on[2];
@@ -841,7 +898,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             } else if constexpr (KWSUM) {
                 __syncthreads();                               // every wave has left the halo: the LDS is free
                 constexpr int ZERO = 16 * 160;                 // a zero float behind the image of a position half: the missing term at j = 0 / 7
-                float* buf = (float*)smem + wpx * (16 * 160 + 4);
+                float* buf = (float*)(smem + (ASMRK ? (size_t)(gbuf ^ 1) * (HI * 4096) : 0)) + wpx * (16 * 160 + 4);      // (ASMR: the buffer the last chunk read)
                 const int th128 = wch * 64 + lane;
                 if (th128 == 0) buf[ZERO] = 0.f;
                 // every thread finishes 3 float4 (12 logits) of the 8 (h) x 176 (j, c) block of a depth slice; the LDS offsets of their two
@@ -912,6 +969,9 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
             }
         CONV_EPILOGUE()
     }
+    if (!ASMRK || !has_next) break;
+    ++p_j;
+    }       // tile loop (persistent mode)
 #ifdef CS_TIMELINE
     TL_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1012,6 +1072,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         }
         kp.in_sample_bytes = (unsigned)(span * 2);
     }
+    kp.persist_total = 0;
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
@@ -1039,6 +1100,11 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
 #ifdef CS_TIMELINE
     kp.tl = g_cs_tl; kp.tl_cap = g_cs_tl_cap;
 #endif
+    if (asmr && db && p.persist_total != 0 && !p.sk_out) {          // persistent: one workgroup per CU (LDS: one resident), XCD x walks entries [x * total / 8 ...)
+        const unsigned total = grid.x * grid.y;
+        kp.persist_total = (int)total;
+        grid = dim3(total < 256u ? (total + 7u) & ~7u : 256u, 1);
+    }
     if (db) {
         auto k = conv_halo_kernel<CK, WPX, WCH, WVP, WVC, MODE, true, SK, ST>;
         if (lds > 64 * 1024) {

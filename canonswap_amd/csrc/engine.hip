@@ -261,6 +261,8 @@ bool enc256() { static const bool v = [] { const char* s = getenv("CANONSWAP_ENC
 bool spade256() { static const bool v = [] { const char* s = getenv("CANONSWAP_SPADE256"); return !s || atoi(s) != 0; }(); return v; }
 bool ragged_on() { static const bool v = [] { const char* s = getenv("CANONSWAP_RAGGED"); return s ? atoi(s) != 0 : true; }(); return v; }
 
+// ConvParams::persist_total request of every engine launch (A/B knob CANONSWAP_HALO_PERSIST=0|1)
+int halo_persist_default() { static const int v = [] { const char* s = getenv("CANONSWAP_HALO_PERSIST"); return s ? atoi(s) : 1; }(); return v; }
 // ConvParams::xcd_map of every engine launch (A/B knob CANONSWAP_XCD_MAP=0|1|2)
 int xcd_map_default()
 {
@@ -369,6 +371,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         const bool spade_ck32 = spade32 && c.mode == MODE_SPADE && !(spade256() && c.p.Cout_pad % 256 == 0);
         const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !spade_ck32) ? 64 : 32;
         c.p.xcd_map = xcd_map_default();
+        c.p.persist_total = halo_persist_default();
         {
             static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
             c.p.ep_general = epg;
@@ -1615,6 +1618,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
         set_tile(p, BM, d->tile_w ? d->tile_w : (is3d ? 8 : 16), d->tile_h ? d->tile_h : (is3d ? 8 : BM / 16));
         const int ck = d->ck ? d->ck : ((!is3d && p.Cin % 64 == 0) ? 64 : 32);
         p.xcd_map = d->xcd_map > 0 ? d->xcd_map - 1 : xcd_map_default();
+        p.persist_total = halo_persist_default();
         p.ragged = d->ragged;
         p.ep_general = d->ep_general;
         return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);

@@ -413,6 +413,40 @@ def test_conv_ragged_last_chunk_paired_taps(k, tile, cfg, cout_pad, cin_real, ci
     assert ops.rel_err(outs[1], outs[0]) < 1e-5          # fp32 accumulation, another order within the last chunk
 
 
+@pytest.mark.parametrize("k,tile,shape,ragged", [((3, 3, 3), (8, 8), (16, 32, 32), True), ((3, 3, 3), (8, 8), (8, 16, 16), False),
+                                                 ((7, 7, 1), (4, 8), (8, 16, 32), True)])
+def test_conv_256x160_tiles_walk_a_tile_list(k, tile, shape, ragged):
+    """The 256 x 160 kernels run persistent (ConvParams::persist_total): a workgroup's first tile is staged by a burst, every later one under
+    the last chunk of its predecessor, with the weight ring carried across the epilogue.  More tiles than workgroups, a count that does not
+    divide by 8 XCDs: against the fp32 reference, and the same sample at two places of the walk gives the same bits."""
+    import hip_ops as ops
+    r = _rng(91 + k[0])
+    D, H, W = shape
+    per = D * H * W // 256
+    N = (2 * 256 + 24) // per + 1                      # > 2 tiles per workgroup on 256 CUs, ragged shares
+    N += N % 2
+    cin_real, cin, cout_pad, Cout = (142, 144, 160, 150) if ragged else (128, 128, 160, 160)
+    xh = _randn(r, N // 2, cin_real, D, H, W)
+    x = torch.cat([xh, xh], 0)
+    w = _randn(r, Cout, cin_real, *k, scale=1.0 / np.sqrt(cin_real * np.prod(k)))
+    b = _randn(r, Cout, scale=0.1)
+    buf = torch.zeros(N, D, H, W, cin, dtype=torch.float16, device=DEV)
+    buf[..., :cin_real] = _to_cl(x).to(DEV)
+    bp = torch.zeros(cout_pad); bp[:Cout] = b
+    wp = ops.packed_weight(w, cout_pad, DEV)
+    if ragged:
+        ops.pair_ragged(wp, cout_pad, cin, k)
+    out = torch.full((N, D, H, W, cout_pad), float("nan"), dtype=torch.float32, device=DEV)
+    ops.conv(buf, wp, cout_pad, cout_pad, k, cin=cin, bias=bp.to(DEV), act0="relu", out0=out, cfg=19, tile=tile, ragged=ragged)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert torch.equal(o[: N // 2], o[N // 2:])
+    for i in (0, N // 2 - 1):                          # a first tile of a workgroup, a later one
+        ref = F.relu(_ref_conv(xh[i:i + 1], w, b, tuple(kk // 2 for kk in k)))
+        assert ops.rel_err(_from_cl(o[i:i + 1, ..., :Cout]), ref) < 2e-3
+    assert Cout == cout_pad or float(o[..., Cout:].abs().max()) == 0.0
+
+
 def test_conv_split_weights_use_fp16_subnormals():
     """pack._hi_lo: for |w| < 2^-3 the W_lo half of a split-precision weight is an fp16 subnormal.  The MFMA must consume it exactly: the conv
     over [x | x] with [W_hi | W_lo] then matches a float64 conv with the unrounded weights to ~2^-18 relative; flushed to zero it would be

@@ -1,10 +1,19 @@
 #!/bin/bash
-# GPU box: alternating bench runs of the shipped library under different environment settings (A/B knobs of engine.hip), same box.
-#   bash tools/ab_env.sh "" "CANONSWAP_DEPHASE_SPADE=8" "CANONSWAP_DEPHASE_SPADE=16"
-mkdir -p gpurun_out/ab_env
-for i in 1 2; do for v in "$@"; do
-  env $v python bench.py --steps 10 --warmup 3 --no-fixed-job --no-cpu-baseline > gpurun_out/ab_env/b.json 2>/dev/null
-  python - <<PY
-import json; d=json.load(open("gpurun_out/ab_env/b.json")); print("env=[$v]", d["value"], d["roofline"]["frac"], d["ms_per_step"])
+# GPU box: alternating bench runs under two environment settings on the same box, then per-layer CSVs of both:
+#   bash tools/ab_env.sh CANONSWAP_HALO_PERSIST=0 CANONSWAP_HALO_PERSIST=1 [rounds] [tag]
+A=$1; B=$2; R=${3:-2}; TAG=${4:-ab_env}
+cd /root/repo; mkdir -p gpurun_out/$TAG
+for i in $(seq $R); do for v in "$A" "$B"; do
+  env $v timeout 600 python bench.py --steps 10 --warmup 3 --no-fixed-job --no-cpu-baseline > gpurun_out/$TAG/b.json 2>gpurun_out/$TAG/b.err
+  python - <<PY | tee -a gpurun_out/$TAG/ab.txt
+import json
+try:
+    d=json.loads(open("gpurun_out/$TAG/b.json").read().strip().splitlines()[-1]); print("env=[$v]", d["value"], d["roofline"]["frac"], d["ms_per_step"], d.get("psnr_db_min"))
+except Exception as e: print("env=[$v] failed", e, open("gpurun_out/$TAG/b.err").read()[-1500:])
 PY
 done; done
+k=0; for v in "$A" "$B"; do
+  env $v CANONSWAP_PROFILE_CSV=/root/repo/gpurun_out/$TAG/layers_$k.csv timeout 600 python bench.py --no-cpu-baseline --no-fixed-job --steps 1 --warmup 2 > /dev/null 2>&1
+  k=$((k+1))
+done
+python tools/cmp_layers.py gpurun_out/$TAG/layers_0.csv gpurun_out/$TAG/layers_1.csv 2>/dev/null | head -24 | tee gpurun_out/$TAG/cmp.txt
