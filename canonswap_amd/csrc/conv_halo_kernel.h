@@ -1055,13 +1055,14 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     constexpr bool big = (BM == 256 && WCH == 5);
     // (double-buffering the three 52 KB chunks of the split-precision volume convs - one workgroup per CU instead of three single-
     // buffered ones - measured 3 % slower on the whole step: profiles/r02_notes.md)
-    const bool db = nck > 1 && 2 * HV * VS <= (big || (WCH == 4 && PAD == 2) ? 128 : 64) * 1024 && HV * SLP <= 256 * HI;
-    size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
 #ifndef CS_NO_ASMRING
     constexpr bool asmr = WCH == 5 && WPX == 8 && WVP == 2 && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD && !SK;      // see the kernel (ASMR)
 #else
     constexpr bool asmr = false;
 #endif
+    // (the ASMR kernels' two buffers are HI DMA pieces each: the 4 x 8 x 8 mask tile's 2 x 76 KB fit the 160 KB of a CU)
+    const bool db = nck > 1 && (asmr ? 2 * HI * 4096 <= 160 * 1024 : 2 * HV * VS <= (big || (WCH == 4 && PAD == 2) ? 128 : 64) * 1024) && HV * SLP <= 256 * HI;
+    size_t lds = (size_t)(db ? 2 : 1) * HV * VS + 16;
     ConvParams kp = p;
     if (asmr && db) {
         lds = (size_t)2 * HI * 4096;          // buffer stride of a whole number of DMA pieces
