@@ -192,8 +192,23 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
         const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
         const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
-        // the eight corners are fetched unconditionally (clamped address, weight 0 outside the volume: fmaf(0, c, a) == a, the same bits as
-        // skipping the corner) so that the loads go out back to back; behind a bounds test each one waited for its own round trip
+        // The eight corners are fetched unconditionally (clamped address, weight 0 outside the volume: fmaf(0, c, a) == a, the same bits as
+        // skipping the corner) so that the loads go out back to back; behind a bounds test each one waited for its own round trip.  Bounds,
+        // clamps and address terms are formed per AXIS (six of each, not twenty-four); a corner's weight is ((wx * wy) * wz) with the
+        // out-of-range factor replaced by 0 - the same bits as the product of the three factors followed by the bounds select (all
+        // factors are >= 0, so the zero is +0 either way; tools/dbg_hash.py printed the same hashes).  No faster than the per-corner form:
+        // the kernel is not VALU-bound.
+        float wx[2], wy[2], wz[2]; int ox[2], oy[2], oz[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int xc = x0 + q, yc = y0 + q, zc = z0 + q;
+            wx[q] = (unsigned)xc < (unsigned)W ? (q ? tx : 1.f - tx) : 0.f;
+            wy[q] = (unsigned)yc < (unsigned)H ? (q ? ty : 1.f - ty) : 0.f;
+            wz[q] = (unsigned)zc < (unsigned)D ? (q ? tz : 1.f - tz) : 0.f;
+            ox[q] = min(max(xc, 0), W - 1) * 4;
+            oy[q] = min(max(yc, 0), H - 1) * (W * 4);
+            oz[q] = min(max(zc, 0), D - 1) * (H * W * 4);
+        }
         h4_t cv[8]; float wv[8];
 #pragma unroll
         for (int dz = 0; dz < 2; ++dz)
@@ -201,12 +216,8 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const int xc = x0 + dx, yc = y0 + dy, zc = z0 + dz;
-                    const bool in = (unsigned)xc < (unsigned)W && (unsigned)yc < (unsigned)H && (unsigned)zc < (unsigned)D;
-                    const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
-                    const int xq = min(max(xc, 0), W - 1), yq = min(max(yc, 0), H - 1), zq = min(max(zc, 0), D - 1);
-                    cv[dz * 4 + dy * 2 + dx] = *(const h4_t*)(base + (((long)zq * H + yq) * W + xq) * 4);
-                    wv[dz * 4 + dy * 2 + dx] = in ? wgt : 0.f;
+                    cv[dz * 4 + dy * 2 + dx] = *(const h4_t*)(base + (oz[dz] + oy[dy] + ox[dx]));
+                    wv[dz * 4 + dy * 2 + dx] = (wx[dx] * wy[dy]) * wz[dz];
                 }
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8)
