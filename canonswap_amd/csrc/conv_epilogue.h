@@ -187,6 +187,17 @@ _Pragma("unroll") \
         } \
     }
 
+// value of lane i + N of the lane's row of 16 (row_shl:N; 0 beyond the row)
+template <int N> __device__ __forceinline__ float ep_row_shl(float a)
+{
+#ifdef EP_HOST_EMULATION          /* the host harness runs one lane at a time and never takes the pooled path */
+    (void)a;
+    return 0.f;
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x100 | N, 0xf, 0xf, true));
+#endif
+}
+
 // Sum over the 16 lanes of a row (the 16 positions of an MFMA block), valid in the row's lane 0, with the bits of the xor butterfly
 // a += shfl_xor(a, 1), 2, 4, 8 there: lane 0 of that butterfly only ever combines values from lanes i and i + o (i a multiple of 2 o), which
 // is what a row shift by o delivers.  As DPP operands of the adds these are 4 VALU instructions; the shuffles were 4 ds_bpermute round
@@ -472,8 +483,8 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
                     float t_ = v[r]; \
-                    t_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t_), 0x100 | (EP_POOL ? (EP_POOL_WSH_V) : 1), 0xf, 0xf, true)); \
-                    t_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t_), 0x100 | (EP_POOL ? (EP_POOL_HSH_V) : 1), 0xf, 0xf, true)); \
+                    t_ += ep_row_shl<(EP_POOL ? (EP_POOL_WSH_V) : 1)>(t_); \
+                    t_ += ep_row_shl<(EP_POOL ? (EP_POOL_HSH_V) : 1)>(t_); \
                     v[r] = t_ * 0.25f; \
                 } \
             } \
