@@ -266,9 +266,10 @@ _Pragma("unroll") \
 #ifndef EP_PIPE_V
 #define EP_PIPE_V 0
 #endif
-/* AvgPool(1,2,2) of out0 inside the epilogue (ConvParams::pool_hw; DownBlock3d, util.py:185-190): the four positions of a window are four
-   lanes of one 16-position block; a kernel that supports it names the two DPP row shifts (in lanes) that reach the w + 1 and h + 1
-   neighbours under its lane -> position map.  0: the kernel has no pooling epilogue. */
+/* AvgPool(1,2,2) of out0 inside the epilogue (ConvParams::pool_hw; DownBlock3d, util.py:185-190; DownBlock2d, util.py:150-165): the four
+   positions of a window are four lanes of one 16-position block; a kernel that supports it names the two DPP row shifts (in lanes) that reach
+   the w + 1 and h + 1 neighbours under its lane -> position map.  WSH > 0 with HSH == 0: the blocks are rows of 16 columns (2-D 16 x 8
+   tiles) and the h + 1 neighbour is the same lane of the next block.  WSH == 0: the kernel has no pooling epilogue. */
 #ifndef EP_POOL_WSH_V
 #define EP_POOL_WSH_V 0
 #define EP_POOL_HSH_V 0
@@ -307,6 +308,8 @@ _Pragma("unroll") \
     constexpr bool EPALL = EPFAST && ((EPF >> 6) & 1) == 0;      /* every channel of the wave exists */ \
     constexpr bool EP_POOL = EPFAST && ((EPF >> 7) & 1) != 0 && (EP_POOL_WSH_V) > 0;      /* out0 = AvgPool(1,2,2) of the activated values, on the pooled grid */ \
     constexpr int EP_PS = EP_POOL ? 1 : 0; \
+    constexpr bool EP_POOL_HB = EP_POOL && (EP_POOL_HSH_V) == 0;      /* 2-D tiles: the h + 1 neighbour is the same lane of the NEXT position block */ \
+    float ep_phold[EP_POOL_HB ? WCH : 1][4];                           /* activated values of the even block, until the odd one arrives */ \
     const bool ep_has_res = EPFAST ? ((EPF & 3) != 0) : (p.res.p != nullptr); \
     const bool ep_res32 = EPFAST ? ((EPF & 3) == 2) : (p.res_f32 != 0); \
     const bool ep_has_o0 = EPFAST ? (((EPF >> 2) & 1) != 0) : (p.out0.p != nullptr); \
@@ -479,7 +482,17 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] *= ps; \
             } \
-            if (EP_POOL) { /* (a + b) + (c + d) over the window, as DPP operands of the adds; x 0.25 */ \
+            if (EP_POOL_HB) { /* (a + c) + (b + d): the block pair in registers, the column pair as a DPP operand; x 0.25 */ \
+_Pragma("unroll") \
+                for (int r = 0; r < 4; ++r) { \
+                    if ((pi & 1) == 0) ep_phold[EP_POOL_HB ? ci : 0][r] = v[r]; \
+                    else { \
+                        float t_ = ep_phold[EP_POOL_HB ? ci : 0][r] + v[r]; \
+                        t_ += ep_row_shl<(EP_POOL ? (EP_POOL_WSH_V) : 1)>(t_); \
+                        v[r] = t_ * 0.25f; \
+                    } \
+                } \
+            } else if (EP_POOL) { /* (a + b) + (c + d) over the window, as DPP operands of the adds; x 0.25 */ \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) { \
                     float t_ = v[r]; \
@@ -489,7 +502,7 @@ _Pragma("unroll") \
                 } \
             } \
             const bool ep_hold = EP_PAIR != 0 && !ep_second(EP_PAIR, ci) && (EPALL || cb + 4 < p.Cout);      /* first half of a complete pair */ \
-            if (ep_has_o0 && ep_pool_lane EP_STORE_COND) { \
+            if (ep_has_o0 && ep_pool_lane && (!EP_POOL_HB || (pi & 1)) EP_STORE_COND) { \
                 if (ep_m0 && ep_hold) { \
 _Pragma("unroll") \
                     for (int r = 0; r < 4; ++r) ep_vh[r] = v[r]; \

@@ -167,6 +167,14 @@ template <int ST, int PAD> constexpr int halo_pool_shift(int bit)
     return 0;
 }
 
+// kernels that carry the 2-D pooling epilogue (conv_epilogue.h, EP_POOL_HB)
+template <int CK, int WPX, int WCH, int WVP, int MODE, bool SK, int ST> constexpr bool halo_pool2d()
+{
+    using SS = StaticShape<ST>;
+    return ST != 0 && !SK && MODE == MODE_STD && CK == 32 && WPX == 8 && WVP == 1 && (WCH == 2 || WCH == 4) && SS::KD == 1 && SS::KH == 3 && SS::KW == 3 &&
+           SS::LW == 4 && SS::LH == 3 && SS::LD == 0;
+}
+
 template <int CK, int WPX, int WCH, int WVP, int WVC, int MODE, bool DB, bool SK, int ST>
 // Resident workgroups per CU the register budget is held to: 2 for the 128x256 tiles (256 VGPRs); 3 for the statically
 // unrolled 128x128 tiles (<= 168 VGPRs, no scratch) -- for short-K convs a third workgroup hides the prologue / epilogue
@@ -183,7 +191,9 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr int SLP = SL + PAD;        // ... plus the pad slot(s) (bank spreading; also fetched, from the zero page)
     // pooling epilogue (ConvParams::pool_hw): 3-D static tiles of 8 or 4 columns - the w and h neighbours of a position lie in its 16-position block
     constexpr bool EP_POOLK = ST != 0 && !SK && MODE == MODE_STD && WCH == 2 && SS::KD == 3 && SS::KH == 3 && SS::KW == 3 && (SS::LW == 3 || SS::LW == 2) && SS::LH >= 1;
-    constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : 0;
+    // ... and the 2-D 16 x 8 tiles of F's down blocks (32-channel chunks: their weights are the [W_hi | W_lo] groups): a block is a row of 16 columns
+    constexpr bool EP_POOLK2 = halo_pool2d<CK, WPX, WCH, WVP, MODE, SK, ST>();
+    constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : (EP_POOLK2 ? 1 : 0);
     constexpr int EP_POOL_HSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(SS::LW) : 0;
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
     // halo pieces per thread whose source offsets are kept in registers (the big halos of the mask conv / 4x4x16 tiles too)
@@ -1020,10 +1030,11 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     if (p.pool_hw) {
         using SSL = StaticShape<ST>;
         constexpr bool poolk = ST != 0 && !SK && MODE == MODE_STD && WCH == 2 && SSL::KD == 3 && SSL::KH == 3 && SSL::KW == 3 && (SSL::LW == 3 || SSL::LW == 2) && SSL::LH >= 1;
-        if (!poolk || p.res.p || p.out1.p || p.pixscale || p.stat_out || p.out0_f32 || !p.out0.p || p.sk_out || p.ep_general || (p.H & 1) || (p.W & 1) ||
+        constexpr bool poolk2 = halo_pool2d<CK, WPX, WCH, WVP, MODE, SK, ST>();
+        if (!(poolk || poolk2) || p.res.p || p.out1.p || p.pixscale || p.stat_out || p.out0_f32 || !p.out0.p || p.sk_out || p.ep_general || (p.H & 1) || (p.W & 1) ||
             p.Cout % 8 || p.Cout != p.Cout_pad || (1 << lgS_of(p)) != BM || ((unsigned long long)p.out0.p & 15ull) ||
             ((p.out0.sN | p.out0.sD | p.out0.sH | p.out0.sW) & 7)) {
-            cs_set_error("conv_halo: pool_hw (AvgPool(1,2,2) in the epilogue) needs a static 3x3x3 tile of 8 or 4 columns with two channel fragments per wave, fp16 out0 only, every packed channel real");
+            cs_set_error("conv_halo: pool_hw (AvgPool(1,2,2) in the epilogue) needs a static 3x3x3 tile of 8 or 4 columns with two channel fragments per wave or a 2-D 16x8 tile with 32-channel chunks, fp16 out0 only, every packed channel real");
             return -1;
         }
     }

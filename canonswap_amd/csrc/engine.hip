@@ -525,14 +525,27 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 {
     TRY(e->run(1, st, [&] { return launch_conv_first(img, e->first_w, e->first_b, e->f_t0, B, IMG, IMG, st); }, "conv_first"));
     e->flops += 2.0 * 3 * 64 * 9 * (double)B * IMG * IMG;
+    // DownBlock2d (util.py:150-165): conv3x3 + folded BN + ReLU + AvgPool2d(2); the pool runs inside the conv's epilogue (ConvParams::pool_hw:
+    // the average of the four fp32 values, one rounding, no full-resolution tensor) where the kernel carries it: the 32-channel-chunk
+    // 16 x 8 tiles the [W_hi | W_lo] weights run on (CANONSWAP_POOL_FOLD=0, latency mode, CANONSWAP_F_WSPLIT=0: the two-launch form)
+    static const bool pool_fold = [] { const char* s = getenv("CANONSWAP_POOL_FOLD"); return !s || atoi(s) != 0; }();
+    const bool fold = pool_fold && !e->latency_mode && f_wsplit();
     ConvCall d0 = mk(e->f_down0, e->f_t0, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
-    d0.p.act0 = ACT_RELU; d0.p.out0 = nhwc(e->f_t1, 256, 256, 128); wsplit_in(d0, 64);
-    TRY(go(e, d0, st));
-    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }, "avgpool"));
+    d0.p.act0 = ACT_RELU; wsplit_in(d0, 64);
+    if (fold) { d0.p.pool_hw = 1; d0.p.out0 = nhwc(e->f_p0, 128, 128, 128); TRY(go(e, d0, st)); }
+    else {
+        d0.p.out0 = nhwc(e->f_t1, 256, 256, 128);
+        TRY(go(e, d0, st));
+        TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }, "avgpool"));
+    }
     ConvCall d1 = mk(e->f_down1, e->f_p0, nhwc(nullptr, 128, 128, 128), B, 1, 128, 128);
-    d1.p.act0 = ACT_RELU; d1.p.out0 = nhwc(e->f_t2, 128, 128, 256); wsplit_in(d1, 128);
-    TRY(go(e, d1, st));
-    TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }, "avgpool"));
+    d1.p.act0 = ACT_RELU; wsplit_in(d1, 128);
+    if (fold) { d1.p.pool_hw = 1; d1.p.out0 = nhwc(e->f_p1, 64, 64, 256); TRY(go(e, d1, st)); }
+    else {
+        d1.p.out0 = nhwc(e->f_t2, 128, 128, 256);
+        TRY(go(e, d1, st));
+        TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }, "avgpool"));
+    }
     *cur = 0;
     ConvCall s = mk(e->f_second, e->f_p1, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);   // 1x1 -> the 32x16 volume
     s.p.out0 = hwdc2(e->vs[0]); s.p.out0_f32 = 1;

@@ -447,6 +447,30 @@ def test_conv_256x160_tiles_walk_a_tile_list(k, tile, shape, ragged):
     assert Cout == cout_pad or float(o[..., Cout:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cfg,N,Cin,Cout,H,W", [(10, 2, 96, 128, 32, 48), (17, 3, 32, 256, 16, 32)])
+def test_conv2d_avgpool_in_the_epilogue(cfg, N, Cin, Cout, H, W):
+    """DownBlock2d (util.py:150-166): conv3x3 + folded BN + ReLU + AvgPool2d(2) as ONE launch on the 16 x 8 tiles with 32-channel chunks (F's
+    down blocks): the h + 1 neighbour of a window is the same lane of the next position block, the w + 1 neighbour a DPP row shift."""
+    import hip_ops as ops
+    r = _rng(500 + cfg)
+    x = F.relu(_randn(r, N, Cin, 1, H, W))
+    w = _randn(r, Cout, Cin, 1, 3, 3, scale=1.0 / np.sqrt(9 * Cin))
+    b = _randn(r, Cout, scale=0.1)
+    ref = F.avg_pool3d(F.relu(_ref_conv(x, w, b, (0, 1, 1))), (1, 2, 2))
+    xd = _to_cl(x).to(DEV)
+    wp = ops.packed_weight(w, Cout, DEV)
+    obuf = torch.full((N, 1, H // 2, W // 2, Cout + 32), -5.0, dtype=torch.float16, device=DEV)
+    ops.conv(xd, wp, Cout, Cout, (1, 3, 3), bias=b.to(DEV), act0="relu", out0=obuf[..., 16:16 + Cout], out_dims=(N, 1, H, W), cfg=cfg, pool_hw=True)
+    torch.cuda.synchronize()
+    assert ops.rel_err(_from_cl(obuf[..., 16:16 + Cout]), ref) < 2e-3
+    assert bool((obuf[..., :16] == -5.0).all()) and bool((obuf[..., 16 + Cout:] == -5.0).all())
+    full = torch.zeros(N, 1, H, W, Cout, dtype=torch.float32, device=DEV)       # the same conv unpooled, fp32: its 2x2 means are the pooled output
+    ops.conv(xd, wp, Cout, Cout, (1, 3, 3), bias=b.to(DEV), act0="relu", out0=full, cfg=cfg)
+    torch.cuda.synchronize()
+    mean4 = full.view(N, 1, H // 2, 2, W // 2, 2, Cout).mean(dim=(3, 5))
+    assert float((obuf[..., 16:16 + Cout].float() - mean4).abs().max()) <= float(mean4.abs().max()) * 2.0 ** -10
+
+
 def test_conv_split_weights_use_fp16_subnormals():
     """pack._hi_lo: for |w| < 2^-3 the W_lo half of a split-precision weight is an fp16 subnormal.  The MFMA must consume it exactly: the conv
     over [x | x] with [W_hi | W_lo] then matches a float64 conv with the unrounded weights to ~2^-18 relative; flushed to zero it would be
