@@ -114,6 +114,9 @@ struct ConvParams {
     // conv_halo, 3-D tiles of 8 or 4 columns, fp16 out0 only: out0 = AvgPool(1,2,2) of act0(conv + bias) computed in the epilogue (DownBlock3d,
     // util.py:185-190); out0's strides address the POOLED grid (h / 2, w / 2).  The average is taken over the fp32 values: one rounding.
     int pool_hw;
+    // mode STD only: out0 = act0(IN(res) * (1 + conv + bias)), IN(res)[n][c] = (res - mean) * rstd with (mean, rstd) = stats[n][c][2] - SPADE's
+    // modulation (util.py:295-302) without its beta half; res fp16 (res_shift as in SPADE), tiles within one sample
+    int spmul;
     // conv_halo's 256 x 160 tiles: != 0 asks for the persistent launch (one workgroup per CU walks a list of tiles, the next tile's first
     // chunk staged under the last chunk of the current one; conv_halo_kernel.h); the launcher replaces it by the number of (tile, channel
     // block) entries, or by 0 where the kernel has no such mode.

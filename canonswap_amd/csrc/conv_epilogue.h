@@ -275,6 +275,13 @@ _Pragma("unroll") \
 #define EP_POOL_HSH_V 0
 #endif
 #define EP_POOLB 128          /* EP_CODE bit: pooled out0 */
+/* ConvParams::spmul (mode STD): out0 = act0(IN(res) * (1 + conv + bias)) with (mean, rstd) from stats - SPADE's modulation without its beta
+   half (util.py:295-302 where beta is applied elsewhere: the learned shortcut of SPADEResnetBlock, engine.hip run_G).  The general epilogue
+   always knows it; a kernel that wants a branch-free copy sets EP_SPMUL_V. */
+#ifndef EP_SPMUL_V
+#define EP_SPMUL_V 0
+#endif
+#define EP_SPMULB 256         /* EP_CODE bit: spmul */
 /* one fetch round of the epilogue: residual / modulated tensor / per-position scale of the position blocks PG0 .. PG0 + EP_G - 1 -> register set BI */
 #define EP_FETCH_ROUND(PG0, BI) \
     if (EP_PF && !EP_EARLY && (ep_fetch || ep_has_ps)) { \
@@ -308,6 +315,7 @@ _Pragma("unroll") \
     constexpr bool EPALL = EPFAST && ((EPF >> 6) & 1) == 0;      /* every channel of the wave exists */ \
     constexpr bool EP_POOL = EPFAST && ((EPF >> 7) & 1) != 0 && (EP_POOL_WSH_V) > 0;      /* out0 = AvgPool(1,2,2) of the activated values, on the pooled grid */ \
     constexpr int EP_PS = EP_POOL ? 1 : 0; \
+    const bool ep_spm = EPFAST ? (((EPF >> 8) & 1) != 0) : ((MODE == MODE_STD) && p.spmul != 0); \
     constexpr bool EP_POOL_HB = EP_POOL && (EP_POOL_HSH_V) == 0;      /* 2-D tiles: the h + 1 neighbour is the same lane of the NEXT position block */ \
     float ep_phold[EP_POOL_HB ? WCH : 1][4];                           /* activated values of the even block, until the odd one arrives */ \
     const bool ep_has_res = EPFAST ? ((EPF & 3) != 0) : (p.res.p != nullptr); \
@@ -327,7 +335,7 @@ _Pragma("unroll") \
         ep_bias2[ci] = (cok && MODE == MODE_SPADE) ? *(const float4*)(p.bias2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
         ep_s2[ci] = (cok && p.s2) ? *(const float4*)(p.s2 + cb) : make_float4(1.f, 1.f, 1.f, 1.f); \
         ep_t2[ci] = (cok && p.s2) ? *(const float4*)(p.t2 + cb) : make_float4(0.f, 0.f, 0.f, 0.f); \
-        if (MODE == MODE_SPADE && cok) { /* SPADE launches tile within one sample: n == tn */ \
+        if ((MODE == MODE_SPADE || ep_spm) && cok) { /* SPADE launches tile within one sample: n == tn */ \
             const float4 q0 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb) * 2); \
             const float4 q1 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb) * 2 + 4); \
             ep_mean[ci] = make_float4(q0.x, q0.z, q1.x, q1.z); ep_rstd[ci] = make_float4(q0.y, q0.w, q1.y, q1.w); \
@@ -362,7 +370,7 @@ _Pragma("unroll") \
     const bool ep_m0 = EP_PAIR != 0 && !ep_o032 && (EPFAST || ep_al8(p.out0)); \
     const bool ep_m1 = EP_PAIR != 0 && (EPFAST || ep_al8(p.out1)); \
     const bool ep_mr = EP_PAIR != 0 && EP_PF && !ep_res32 && (EPFAST || ep_al8(p.res)); \
-    const int ep_rshift = (MODE == MODE_SPADE) ? p.res_shift : 0; \
+    const int ep_rshift = (MODE == MODE_SPADE || ep_spm) ? p.res_shift : 0; \
     /* Addressing.  A position of the tile is m = blk * 16 + l15 with blk = ep_wpx * EP_WPX + pi uniform over the wave; the tile's \
        (w, h, d, n) are disjoint bit fields of m, so every coordinate - also after the >> of an up-sampled operand - is the sum of a \
        lane part (bits of l15) and a block part (bits of blk), and every element offset (a linear form in the coordinates) is \
@@ -372,7 +380,7 @@ _Pragma("unroll") \
     int ep_lw, ep_lh, ep_ld, ep_ln; \
     { int t = l15p; ep_lw = t & mW; t >>= lgTW; ep_lh = t & mH; t >>= lgTH; ep_ld = t & mD; t >>= lgTD; ep_ln = t; } \
     const int ep_w0 = tw << lgTW, ep_h0 = th << lgTH, ep_d0 = td << lgTD, ep_nb = tn * (BM >> lgS); \
-    const int ep_rs = (MODE == MODE_SPADE) ? p.res_shift : 0; \
+    const int ep_rs = (MODE == MODE_SPADE || ep_spm) ? p.res_shift : 0; \
     /* per-axis products as 24-bit multiplies (full rate; coordinates are small, launchers refuse axis strides >= 2^23); the \
        sample term only where a tile spans several samples */ \
     const bool ep_tn1 = (BM >> lgS) == 1; \
@@ -458,6 +466,10 @@ _Pragma("unroll") \
             } else { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] = ep_acc[ci][pi][r] + ((const float*)&ep_bias[ci])[r]; \
+                if (ep_spm) { \
+_Pragma("unroll") \
+                    for (int r = 0; r < 4; ++r) v[r] = ((rr[r] - ((const float*)&ep_mean[ci])[r]) * ((const float*)&ep_rstd[ci])[r]) * (1.f + v[r]); \
+                } \
             } \
 _Pragma("unroll") \
             for (int r = 0; r < 4; ++r) v[r] = EP_HEAVY ? apply_act(v[r], p.act0, p.slope0) : lin_act(v[r], ep_sl0); \
@@ -474,7 +486,7 @@ _Pragma("unroll") \
             } \
             /* no residual: rr == 0; no per-position scale: ps == 1 - applied unconditionally (a select per element costs more issue \
                slots than the add / multiply it would skip; the epilogue is VALU-issue-bound, profiles/r02_store_ablation.txt) */ \
-            if (MODE != MODE_SPADE) { \
+            if (MODE != MODE_SPADE && !ep_spm) { \
 _Pragma("unroll") \
                 for (int r = 0; r < 4; ++r) v[r] += rr[r]; \
             } \
@@ -561,7 +573,7 @@ _Pragma("unroll") \
                                (!p.res.p || p.res_f32 || EP_PAIR == 0 || ep_al8(p.res)) && \
                                (!p.out0.p || p.out0_f32 || EP_PAIR == 0 || ep_al8(p.out0)) && (!p.out1.p || EP_PAIR == 0 || ep_al8(p.out1)); \
             if (ep_ok) ep_code = EP_CODE(p.res.p ? (p.res_f32 ? 2 : 1) : 0, p.out0.p ? 1 : 0, p.out0_f32 ? 1 : 0, p.out1.p ? 1 : 0, p.pixscale ? 1 : 0) | \
-                                 (ep_call ? 0 : EP_RAGGED) | (p.pool_hw ? EP_POOLB : 0); \
+                                 (ep_call ? 0 : EP_RAGGED) | (p.pool_hw ? EP_POOLB : 0) | ((MODE == MODE_STD && p.spmul) ? EP_SPMULB : 0); \
         } \
         bool ep_done = false; \
         if constexpr (EP_FAST && MODE == MODE_SPADE) { \
@@ -572,6 +584,9 @@ _Pragma("unroll") \
         } \
         if constexpr (MODE == MODE_STD && (EP_POOL_WSH_V) > 0) { \
             if (ep_code == (EP_CODE(0, 1, 0, 0, 0) | EP_POOLB)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 0, 0, 0) | EP_POOLB); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && MODE == MODE_STD && (EP_SPMUL_V)) { \
+            if (ep_code == (EP_CODE(1, 1, 0, 0, 0) | EP_SPMULB)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 1, 0, 0, 0) | EP_SPMULB); ep_done = true; } \
         } \
         if constexpr (EP_FAST && (MODE == MODE_STD || MODE == MODE_STDSTAT) && WCH != 5) { \
             if (ep_code == EP_CODE(1, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 1, 0, 0, 0)); ep_done = true; } \

@@ -25,6 +25,7 @@
 #endif
 #define EP_POOL_WSH_V EP_POOL_WSH_K      /* lane shifts of the pooling epilogue: per instantiation, from the lane -> position map (below) */
 #define EP_POOL_HSH_V EP_POOL_HSH_K
+#define EP_SPMUL_V EP_SPMUL_K            /* kernels that carry a branch-free copy of the spmul epilogue (below) */
 #include "conv_epilogue.h"
 
 // Weight fragments are streamed with loads the compiler does not track (inline asm) and are waited for with an
@@ -193,6 +194,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr bool EP_POOLK = ST != 0 && !SK && MODE == MODE_STD && WCH == 2 && SS::KD == 3 && SS::KH == 3 && SS::KW == 3 && (SS::LW == 3 || SS::LW == 2) && SS::LH >= 1;
     // ... and the 2-D 16 x 8 tiles of F's down blocks (32-channel chunks: their weights are the [W_hi | W_lo] groups): a block is a row of 16 columns
     constexpr bool EP_POOLK2 = halo_pool2d<CK, WPX, WCH, WVP, MODE, SK, ST>();
+    // ConvParams::spmul: the 128 x 256 tiles the gamma convs of G's two learned shortcuts run on
+#ifdef CS_NO_SPMUL_FAST
+    constexpr bool EP_SPMUL_K = false;
+#else
+    constexpr bool EP_SPMUL_K = ST == 1 && !SK && MODE == MODE_STD && CK == 64 && WCH == 4 && WPX == 8 && WVP == 1;
+#endif
     constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : (EP_POOLK2 ? 1 : 0);
     constexpr int EP_POOL_HSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(SS::LW) : 0;
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
@@ -1035,6 +1042,13 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
             p.Cout % 8 || p.Cout != p.Cout_pad || (1 << lgS_of(p)) != BM || ((unsigned long long)p.out0.p & 15ull) ||
             ((p.out0.sN | p.out0.sD | p.out0.sH | p.out0.sW) & 7)) {
             cs_set_error("conv_halo: pool_hw (AvgPool(1,2,2) in the epilogue) needs a static 3x3x3 tile of 8 or 4 columns with two channel fragments per wave or a 2-D 16x8 tile with 32-channel chunks, fp16 out0 only, every packed channel real");
+            return -1;
+        }
+    }
+    if (p.spmul) {
+        if (MODE != MODE_STD || SK || !p.res.p || p.res_f32 || !p.stats || p.out1.p || p.pixscale || p.stat_out || p.pool_hw || p.sk_out || p.kw_out ||
+            (1 << lgS_of(p)) != BM) {
+            cs_set_error("conv_halo: spmul (out0 = act0(IN(res) (1 + conv))) is a mode-STD epilogue with an fp16 res, stats, one output and tiles within one sample");
             return -1;
         }
     }

@@ -387,7 +387,7 @@ int wide_ep_code(const ConvParams& p)
 // tensor combinations compiled below; enough tiles to give every workgroup of the persistent grid the same number of items.
 bool conv_wide_supported(const ConvParams& p, int mode)
 {
-    if (p.KD != 1 || p.KH != 3 || p.KW != 3 || p.D != 1 || p.inD != 1 || p.up_shift || p.cg || p.hilo || p.ragged || p.sk_out || p.kw_out || p.xf_kind) return false;
+    if (p.KD != 1 || p.KH != 3 || p.KW != 3 || p.D != 1 || p.inD != 1 || p.up_shift || p.cg || p.hilo || p.ragged || p.sk_out || p.kw_out || p.xf_kind || p.spmul || p.pool_hw) return false;
     if (p.H % 16 || p.W % 16 || p.Cin % 64 || p.Cout_pad % 256 || p.Cout_pad > 1024) return false;
     if (p.ep_general) return false;
     if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;

@@ -85,7 +85,7 @@ struct cs_engine {
     struct ShPhase { ConvL conv; int a, b0, ph, pw; };     // mlp_shared convs of the up blocks per output phase group on the source grid
     ShPhase g_shp[2][12]; int g_nshp[2] = {0, 0};
     struct GB { ConvL conv; const float *bg, *bb; };
-    struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs; bool learned; int fin, fmid, fout; } g_blk[8];
+    struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs, ng, bs; bool learned; int fin, fmid, fout; } g_blk[8];      // ng / bs: the learned shortcut's norm_s, see run_G
 
     // motion extractor (optional: present when the "M.*" blobs were uploaded)
     bool has_m = false;
@@ -112,6 +112,7 @@ struct cs_engine {
     float* stats_pool; float* stats_part; float* dm_occpart; size_t stats_slots = 0, stats_next = 0; size_t stats_slot_floats = 0;
     half_t *g_x[2], *g_h64, *g_dx64, *g_a64, *g_a128, *g_a256, *g_h128, *g_xs128, *g_dx128, *g_h1_128, *g_o128;
     half_t *g_h256, *g_xs256, *g_dx256, *g_h1_256, *g_o256;
+    half_t* g_bs;         // the beta term of a learned shortcut (conv_s o mlp_beta of norm_s)
     float *img_a, *img_b;
 
     // ---- profiling
@@ -880,6 +881,36 @@ int spade_gb(cs_engine* e, const cs_engine::GB& gb, int C, const half_t* actv, i
     return go(e, c, st);   // 128x128 tiles, three resident workgroups per CU (pick_halo_cfg)
 }
 
+// The learned shortcut of a SPADEResnetBlock (util.py:329-344, `x_s = conv_s(norm_s(x, seg))`): no activation sits between SPADE's output
+// IN(x)(1 + gamma) + beta and the 1x1 conv_s, so the beta half is a composition of two linear maps,
+//     conv_s(beta) = conv3x3(actv; W_s W_beta) + W_s b_beta      (one conv 128 -> fout, weights composed at load time, pack.py),
+// and only gamma has to be produced per input channel:  x_s = conv_s(IN(x)(1 + gamma)) + conv_s(beta).  Against the fused gamma/beta launch
+// this drops the 128 -> fin beta conv (half of it) for a 128 -> fout one: up_0 512 -> 256, up_1 256 -> 64 channels at 128^2 / 256^2.
+int spade_shortcut(cs_engine* e, const cs_engine::SpadeBlk& K, const half_t* actv, int astride, int aoff, int B, int S, const half_t* x,
+                   const float* stats, half_t* h, half_t* xs, hipStream_t st)
+{
+    static const bool algebra = [] { const char* s = getenv("CANONSWAP_SHORTCUT_ALGEBRA"); return !s || atoi(s) != 0; }();
+    if (!algebra) {        // the reference's order: fused gamma/beta launch, then conv_s
+        TRY(spade_gb(e, K.ns, K.fin, actv, astride, aoff, B, S, x, 1, stats, ACT_NONE, h, st));
+        ConvCall cs = mk(K.cs, h, nhwc(nullptr, S, S, K.fin), B, 1, S, S);
+        cs.p.out0 = nhwc(xs, S, S, K.fout);
+        return go(e, cs, st);
+    }
+    ConvCall bs = mk(K.bs, actv + aoff, nhwc(nullptr, S, S, astride), B, 1, S, S);       // conv_s(beta)
+    bs.p.out0 = nhwc(e->g_bs, S, S, K.fout);
+    TRY(go(e, bs, st));
+    ConvCall ng = mk(K.ng, actv + aoff, nhwc(nullptr, S, S, astride), B, 1, S, S);       // h = IN(x)(1 + gamma): ConvParams::spmul
+    ng.p.spmul = 1;
+    ng.p.res = nhwc((void*)x, S / 2, S / 2, K.fin); ng.p.res_f32 = 0; ng.p.res_shift = 1;   // nn.Upsample(x2) folded into the addressing
+    ng.p.stats = stats;
+    ng.p.out0 = nhwc(h, S, S, K.fin);
+    TRY(go(e, ng, st));
+    ConvCall cs = mk(K.cs, h, nhwc(nullptr, S, S, K.fin), B, 1, S, S);
+    cs.p.res = nhwc(e->g_bs, S, S, K.fout);
+    cs.p.out0 = nhwc(xs, S, S, K.fout);
+    return go(e, cs, st);
+}
+
 int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
 {
     ConvCall fc = mk(e->g_fc, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
@@ -932,10 +963,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     {
         const cs_engine::SpadeBlk& K = e->g_blk[6];
         const half_t* x = e->g_x[cx];   // nearest up-sampling leaves per-channel mean / variance unchanged: sx still applies
-        TRY(spade_gb(e, K.ns, 512, e->g_a128, 384, 256, B, 128, x, 1, sx, ACT_NONE, e->g_h128, st));
-        ConvCall cs = mk(K.cs, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
-        cs.p.out0 = nhwc(e->g_xs128, 128, 128, 256);
-        TRY(go(e, cs, st));
+        TRY(spade_shortcut(e, K, e->g_a128, 384, 256, B, 128, x, sx, e->g_h128, e->g_xs128, st));
         TRY(spade_gb(e, K.n0, 512, e->g_a128, 384, 0, B, 128, x, 1, sx, ACT_LRELU, e->g_h128, st));
         ConvCall c0 = mk(K.c0, e->g_h128, nhwc(nullptr, 128, 128, 512), B, 1, 128, 128);
         c0.p.out0 = nhwc(e->g_dx128, 128, 128, 256);
@@ -951,10 +979,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     {
         const cs_engine::SpadeBlk& K = e->g_blk[7];
         const half_t* x = e->g_o128;
-        TRY(spade_gb(e, K.ns, 256, e->g_a256, 384, 256, B, 256, x, 1, sx, ACT_NONE, e->g_h256, st));
-        ConvCall cs = mk(K.cs, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
-        cs.p.out0 = nhwc(e->g_xs256, 256, 256, 64);
-        TRY(go(e, cs, st));
+        TRY(spade_shortcut(e, K, e->g_a256, 384, 256, B, 256, x, sx, e->g_h256, e->g_xs256, st));
         TRY(spade_gb(e, K.n0, 256, e->g_a256, 384, 0, B, 256, x, 1, sx, ACT_LRELU, e->g_h256, st));
         ConvCall c0 = mk(K.c0, e->g_h256, nhwc(nullptr, 256, 256, 256), B, 1, 256, 256);
         c0.p.out0 = nhwc(e->g_dx256, 256, 256, 64);
@@ -1090,6 +1115,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     A(g_o128, B * 16384 * 256);
     A(g_h256, B * 65536 * 256); A(g_xs256, B * 65536 * 64); A(g_dx256, B * 65536 * 64); A(g_h1_256, B * 65536 * 64);
     A(g_o256, B * 65536 * 64);
+    A(g_bs, B * 65536 * 64);
     A(img_a, B * 3 * 512 * 512); A(img_b, B * 3 * 512 * 512);
 #undef A
     // the concat buffers carry zero pad channels that are never written: clear once
@@ -1289,7 +1315,11 @@ extern "C" int cs_finalize_weights(cs_engine* e)
         TRY(get_conv(e, b + ".c0", K.fin, K.fmid, K.fmid, 1, 3, 3, K.fmid, (double)K.fin * K.fmid * 9, &K.c0));
         TRY(get_conv(e, b + ".c1", K.fmid, K.fout, K.fout, 1, 3, 3, K.fout, (double)K.fmid * K.fout * 9, &K.c1));
         if (K.learned) {
+            // norm_s (pack.py _pack_G): its gamma conv alone, and conv_s o mlp_beta as one 3x3 conv 128 -> fout.  MACs: what the reference executes
+            // (gamma + beta convs 128 -> 2 fin) is booked on the first, the composed conv is executed work only
             TRY(get_gb(b + ".ns", K.fin, &K.ns));
+            TRY(get_conv(e, b + ".ng", 128, K.fin, K.fin, 1, 3, 3, K.fin, 128.0 * 2 * K.fin * 9, &K.ng));
+            TRY(get_conv(e, b + ".bs", 128, K.fout, K.fout, 1, 3, 3, K.fout, 0.0, &K.bs));
             TRY(get_conv(e, b + ".cs", K.fin, K.fout, K.fout, 1, 1, 1, K.fout, (double)K.fin * K.fout, &K.cs));
         }
     }
@@ -1622,6 +1652,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
         p.xf_stats = d->xf_stats; p.xf_gamma = d->xf_gamma; p.xf_beta = d->xf_beta; p.xf_slope = d->xf_slope;
     }
     c.mode = d->mode;
+    if (d->mode == 5) { c.mode = MODE_STD; p.spmul = 1; }     // out0 = act0(IN(res) (1 + conv + bias)): ConvParams::spmul
     if (d->cfg == CFG_VOL32) return launch_vol32(p, (hipStream_t)stream);
     if (d->cfg == CFG_WIDE) return launch_conv_wide(p, c.mode, (hipStream_t)stream);
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo

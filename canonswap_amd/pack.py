@@ -305,10 +305,19 @@ def _pack_G(out, sd):
             out[f"{n}.c{k}.w"] = pack_conv(w, w.shape[0])
             out[f"{n}.c{k}.b"] = _f32(sd[f"{p}.conv_{k}.bias"])
         if p + ".conv_s.weight_orig" in sd:
-            _pack_gb(out, f"{n}.ns", sd, f"{p}.norm_s")
-            w = spectral_weight(sd, f"{p}.conv_s")
-            out[f"{n}.cs.w"] = pack_conv(w, w.shape[0])
-            out[f"{n}.cs.b"] = _f32(np.zeros(w.shape[0]))
+            # learned shortcut x_s = conv_s(norm_s(x, seg)) (util.py:329-344): no activation between SPADE's IN(x)(1 + gamma) + beta and the
+            # bias-free 1x1 conv_s, so conv_s(beta) = conv3x3(actv; W_s W_beta) + W_s b_beta is ONE conv 128 -> fout (composed here in
+            # float64) and only gamma is computed per input channel (engine.hip spade_shortcut)
+            _pack_gb(out, f"{n}.ns", sd, f"{p}.norm_s")       # the fused gamma/beta form (CANONSWAP_SHORTCUT_ALGEBRA=0: the A/B knob)
+            ws = spectral_weight(sd, f"{p}.conv_s").astype(np.float64)                  # [fout, fin, 1, 1]
+            wg, wb = sd[f"{p}.norm_s.mlp_gamma.weight"], sd[f"{p}.norm_s.mlp_beta.weight"].astype(np.float64)     # [fin, 128, 3, 3]
+            out[f"{n}.ng.w"] = pack_conv(wg, wg.shape[0])
+            out[f"{n}.ng.b"] = _f32(sd[f"{p}.norm_s.mlp_gamma.bias"])
+            wbs = np.einsum("oc,cjhw->ojhw", ws[:, :, 0, 0], wb)
+            out[f"{n}.bs.w"] = pack_conv(wbs, wbs.shape[0])
+            out[f"{n}.bs.b"] = _f32(ws[:, :, 0, 0] @ sd[f"{p}.norm_s.mlp_beta.bias"].astype(np.float64))
+            out[f"{n}.cs.w"] = pack_conv(ws, ws.shape[0])
+            out[f"{n}.cs.b"] = _f32(np.zeros(ws.shape[0]))
     out["G.img.w"] = pack_conv(sd["conv_img.0.weight"], 16)
     out["G.img.b"] = _f32(_pad(sd["conv_img.0.bias"], 16))
 

@@ -181,6 +181,41 @@ def test_conv_spade(xshift, kern):
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
 
 
+@pytest.mark.parametrize("cfg,Cc,ep_general", [(17, 256, False), (17, 256, True), (10, 128, False)])
+@pytest.mark.parametrize("xshift", [0, 1])
+def test_conv_spade_gamma_only(xshift, cfg, Cc, ep_general):
+    """cs_conv_desc.mode 5: out0 = act0(IN(x) (1 + conv + bias)) - SPADE's modulation (util.py:295-302) without the beta half, which the
+    learned shortcut of a SPADEResnetBlock folds into conv_s (engine.hip spade_shortcut).  128 x 256 tiles: the branch-free copy and the
+    general epilogue give the same bits; 128 x 128 tiles only have the general one."""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(140 + xshift + cfg)
+    N, S = 2, 32
+    Sx = S >> xshift
+    actv = F.relu(_randn(r, N, 128, S, S))
+    x = _randn(r, N, Cc, Sx, Sx) * 2 + 0.5
+    wg = _randn(r, Cc, 128, 3, 3, scale=0.02)
+    bg = _randn(r, Cc, scale=0.1)
+    xq = x.half().float()
+    xn = (xq - xq.mean((2, 3), keepdim=True)) / torch.sqrt(xq.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
+    if xshift:
+        xn = xn.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = xn * (1 + F.conv2d(actv.half().float(), wg.half().float(), bg, padding=1))
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    stats = ops.chan_stats(xd.reshape(N, Sx * Sx, Cc))
+    wp = torch.from_numpy(pack.pack_conv(wg.numpy(), Cc)).to(DEV)
+    outs = []
+    for g in ([False, True] if not ep_general else [True]):
+        out = torch.zeros(N, 1, S, S, Cc, dtype=torch.float16, device=DEV)
+        ops.conv(_to_cl(actv).to(DEV), wp, Cc, Cc, (1, 3, 3), bias=bg.to(DEV), res=xd.unsqueeze(1), res_shift=xshift, stats=stats, out0=out, mode=5, cfg=cfg,
+                 ep_general=g)
+        torch.cuda.synchronize()
+        assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
+        outs.append(out.cpu())
+    if len(outs) == 2:
+        assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("kern", KERNELS)
 def test_conv_pixel_shuffle_sigmoid(kern):
     """conv 64->12 + PixelShuffle(2) + sigmoid (spade_generator.py:36-39,56-57)."""
