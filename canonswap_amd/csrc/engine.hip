@@ -389,7 +389,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const int nck = (c.p.Cin + ck - 1) / ck;
             const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
             const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
-                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0;
+                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0 && !c.p.pool_hw && !c.p.spmul;
             static const int sk_maxwg = [] { const char* s = getenv("CANONSWAP_SK_MAXWG"); return s ? atoi(s) : 64; }();   // r02 sweep
             static const int sk_fill = [] { const char* s = getenv("CANONSWAP_SK_FILL"); return s ? atoi(s) : 512; }();
             if (sk_on && plain && wgs <= sk_maxwg && nck >= 4 && e->sk_buf) {
@@ -528,9 +528,9 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
     e->flops += 2.0 * 3 * 64 * 9 * (double)B * IMG * IMG;
     // DownBlock2d (util.py:150-165): conv3x3 + folded BN + ReLU + AvgPool2d(2); the pool runs inside the conv's epilogue (ConvParams::pool_hw:
     // the average of the four fp32 values, one rounding, no full-resolution tensor) where the kernel carries it: the 32-channel-chunk
-    // 16 x 8 tiles the [W_hi | W_lo] weights run on (CANONSWAP_POOL_FOLD=0, latency mode, CANONSWAP_F_WSPLIT=0: the two-launch form)
+    // 16 x 8 tiles the [W_hi | W_lo] weights run on (CANONSWAP_POOL_FOLD=0, CANONSWAP_F_WSPLIT=0: the two-launch form)
     static const bool pool_fold = [] { const char* s = getenv("CANONSWAP_POOL_FOLD"); return !s || atoi(s) != 0; }();
-    const bool fold = pool_fold && !e->latency_mode && f_wsplit();
+    const bool fold = pool_fold && f_wsplit();       // (also in latency mode: these launches are 512 / 256 workgroups, never split-K)
     ConvCall d0 = mk(e->f_down0, e->f_t0, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
     d0.p.act0 = ACT_RELU; wsplit_in(d0, 64);
     if (fold) { d0.p.pool_hw = 1; d0.p.out0 = nhwc(e->f_p0, 128, 128, 128); TRY(go(e, d0, st)); }
