@@ -117,6 +117,10 @@ struct ConvParams {
     // mode STD only: out0 = act0(IN(res) * (1 + conv + bias)), IN(res)[n][c] = (res - mean) * rstd with (mean, rstd) = stats[n][c][2] - SPADE's
     // modulation (util.py:295-302) without its beta half; res fp16 (res_shift as in SPADE), tiles within one sample
     int spmul;
+    // spmul launches whose 256 packed channels are ALL channels of the modulated tensor (the 128 x 256 tile kernel, G's up_1 shortcut): the
+    // 1x1 conv_s that consumes h = IN(res)(1 + conv) runs inside the epilogue - xs_out (fp16, xs_cout <= 64 channels) = xs_w h + xs_res; h is
+    // not stored (out0 == nullptr).  xs_w: packed [Cout / 32][64][32] (pack_conv of the 1x1 weight).  conv_halo_kernel.h, XSK.
+    const half_t* xs_w; TDesc xs_res, xs_out; int xs_cout;
     // conv_halo's 256 x 160 tiles: != 0 asks for the persistent launch (one workgroup per CU walks a list of tiles, the next tile's first
     // chunk staged under the last chunk of the current one; conv_halo_kernel.h); the launcher replaces it by the number of (tile, channel
     // block) entries, or by 0 where the kernel has no such mode.

@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // ... and the 2-D 16 x 8 tiles of F's down blocks (32-channel chunks: their weights are the [W_hi | W_lo] groups): a block is a row of 16 columns
     constexpr bool EP_POOLK2 = halo_pool2d<CK, WPX, WCH, WVP, MODE, SK, ST>();
     // ConvParams::spmul: the 128 x 256 tiles the gamma convs of G's two learned shortcuts run on
+    constexpr bool XSK = ST == 1 && !SK && MODE == MODE_STD && CK == 64 && WCH == 4 && WPX == 8 && WVP == 1;       // ConvParams::xs_w (the fused shortcut epilogue)
 #ifdef CS_NO_SPMUL_FAST
     constexpr bool EP_SPMUL_K = false;
 #else
@@ -861,6 +862,101 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                 for (int ci = 0; ci < WCH; ++ci)
                     *(f4_t*)(p.sk_out + ((long)blockIdx.z * mtot + pos) * p.Cout_pad + ep_chan(EP_PAIR, 1, n0 + wch * WCH * 16, ci, l4)) = acc[ci][pi];
             }
+        } else if (XSK && p.xs_w) {
+            // ---- learned shortcut of a SPADEResnetBlock, fused (ConvParams::xs_w; util.py:329-344): the tile holds ALL 256 channels of
+            // h = IN(x)(1 + gamma) for its 128 positions - wave wch the 64 channels wch * 64 ..., a lane 8 consecutive ones per fragment pair
+            // (EP_PAIR 1), which is exactly the B operand of a 32-deep MFMA step (k = l4 * 8 ...).  So conv_s (1x1, 256 -> 64) runs on the
+            // values in registers: per 16-position block 4 (output fragments) x 2 (32-channel groups) MFMAs per wave, the four waves' partial
+            // sums meet in LDS (fixed order: wave 0 + 1 + 2 + 3), wave w adds conv_s(beta) (xs_res) to output fragment w and stores 16 x 16
+            // fp16 values.  h never goes to HBM (2.1 GB per 64-frame launch at 256^2) and the conv_s launch disappears.
+            if constexpr (XSK) {
+                __syncthreads();                               // every wave has left the halo: the LDS is free
+                float* part = (float*)smem;                    // [2 buffers][4 waves][4 fragments][64 lanes] float4
+                const int cw0 = n0 + wch * 64;                 // this wave's first channel
+                h8_t wsA[4][2];
+#pragma unroll
+                for (int of = 0; of < 4; ++of)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        wsA[of][q] = *(const h8_t*)(p.xs_w + ((long)((cw0 >> 5) + q) * 64 + of * 16 + l15) * 32 + l4 * 8);
+                float gb[2][8], mu[2][8], rs[2][8];            // gamma bias, mean, rstd of the lane's 2 x 8 channels
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cb = cw0 + q * 32 + l4 * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 4) {
+                        const float4 b4 = p.bias ? *(const float4*)(p.bias + cb + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        gb[q][j] = b4.x; gb[q][j + 1] = b4.y; gb[q][j + 2] = b4.z; gb[q][j + 3] = b4.w;
+                        const float4 q0 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb + j) * 2);
+                        const float4 q1 = *(const float4*)(p.stats + ((long)tn * p.Cout + cb + j) * 2 + 4);
+                        mu[q][j] = q0.x; rs[q][j] = q0.y; mu[q][j + 1] = q0.z; rs[q][j + 1] = q0.w;
+                        mu[q][j + 2] = q1.x; rs[q][j + 2] = q1.y; mu[q][j + 3] = q1.z; rs[q][j + 3] = q1.w;
+                    }
+                }
+                const int rsh = p.res_shift;
+                const half_t* xrow = (const half_t*)p.res.p + (long)tn * p.res.sN + cw0 + l4 * 8;
+                const int ow = (tw << lgTW) + l15p, oh0 = th << lgTH;          // 16 x 8 tile: block pi is row oh0 + pi
+                auto xfetch = [&](int pi, int q) -> u4_t {
+                    return *(const u4_t*)(xrow + (long)((oh0 + pi) >> rsh) * p.res.sH + (long)(ow >> rsh) * p.res.sW + q * 32);
+                };
+                u4_t xr[2] = {xfetch(0, 0), xfetch(0, 1)};
+                const int oc = wave * 16 + l4 * 4;             // reduction phase: this lane's 4 output channels (fragment = wave)
+                const bool has_b = p.xs_res.p != nullptr && oc < p.xs_cout;
+                auto bfetch = [&](int pi) -> h4_t {            // conv_s(beta) of this lane's outputs, fetched one block ahead like x
+                    return *(const h4_t*)((const half_t*)p.xs_res.p + ((long)tn * p.xs_res.sN + (long)(oh0 + pi) * p.xs_res.sH + (long)ow * p.xs_res.sW + oc));
+                };
+                h4_t br = (h4_t){0, 0, 0, 0};
+                if (has_b) br = bfetch(0);
+#pragma unroll
+                for (int pi = 0; pi < WPX; ++pi) {
+                    u4_t xn[2] = {xr[0], xr[1]};
+                    h4_t bn = br;
+                    if (pi + 1 < WPX) { xn[0] = xfetch(pi + 1, 0); xn[1] = xfetch(pi + 1, 1); if (has_b) bn = bfetch(pi + 1); }
+                    h8_t hB[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const h8_t xh = __builtin_bit_cast(h8_t, xr[q]);
+                        unsigned pk[4];
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            float v2[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int jj = j + e;
+                                const float g = acc[2 * q + (jj >> 2)][pi][jj & 3] + gb[q][jj];
+                                v2[e] = (((float)xh[jj] - mu[q][jj]) * rs[q][jj]) * (1.f + g);        // the spmul epilogue's arithmetic (conv_epilogue.h)
+                            }
+                            pk[j >> 1] = ep_pk(v2[0], v2[1]);
+                        }
+                        u4_t t4; t4[0] = pk[0]; t4[1] = pk[1]; t4[2] = pk[2]; t4[3] = pk[3];
+                        hB[q] = __builtin_bit_cast(h8_t, t4);
+                    }
+                    float* pb = part + (size_t)(pi & 1) * (4 * 4 * 64 * 4);
+#pragma unroll
+                    for (int of = 0; of < 4; ++of) {
+                        f4_t a = (f4_t){0.f, 0.f, 0.f, 0.f};
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsA[of][0], hB[0], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsA[of][1], hB[1], a, 0, 0, 0);
+                        *(f4_t*)(pb + ((wave * 4 + of) * 64 + lane) * 4) = a;
+                    }
+                    __syncthreads();                           // (two LDS buffers: the next block's writes do not wait for this block's reads)
+                    f4_t sum = *(const f4_t*)(pb + ((0 * 4 + wave) * 64 + lane) * 4);
+#pragma unroll
+                    for (int w2 = 1; w2 < 4; ++w2) {
+                        const f4_t t = *(const f4_t*)(pb + ((w2 * 4 + wave) * 64 + lane) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[r] += t[r];
+                    }
+                    if (oc < p.xs_cout) {
+                        const long po = (long)tn * p.xs_out.sN + (long)(oh0 + pi) * p.xs_out.sH + (long)ow * p.xs_out.sW + oc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[r] += (float)br[r];
+                        ep_u2_t o2; o2[0] = ep_pk(sum[0], sum[1]); o2[1] = ep_pk(sum[2], sum[3]);
+                        *(ep_u2_t*)((half_t*)p.xs_out.p + po) = o2;
+                    }
+                    xr[0] = xn[0]; xr[1] = xn[1]; br = bn;
+                }
+            }
         } else if (KWSUM && p.kw_out) {
             // ---- mask conv: in-tile sum over kw (ConvParams::kw_out).  Tile 2 (w) x 8 (h) x 16 (d); a 16-position block of a wave is the
             // depth slice d = wpx * 8 + pi with l15p = (h << 1) | w'.  Per depth slice the two channel waves of a position half lay their
@@ -1049,6 +1145,16 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         if (MODE != MODE_STD || SK || !p.res.p || p.res_f32 || !p.stats || p.out1.p || p.pixscale || p.stat_out || p.pool_hw || p.sk_out || p.kw_out ||
             (1 << lgS_of(p)) != BM) {
             cs_set_error("conv_halo: spmul (out0 = act0(IN(res) (1 + conv))) is a mode-STD epilogue with an fp16 res, stats, one output and tiles within one sample");
+            return -1;
+        }
+    }
+    if (p.xs_w) {
+        constexpr bool xsk = ST == 1 && !SK && MODE == MODE_STD && CK == 64 && WCH == 4 && WPX == 8 && WVP == 1;
+        if (!xsk || !p.spmul || p.out0.p || p.Cout != 256 || p.Cout_pad != 256 || p.xs_cout < 4 || p.xs_cout > 64 || p.xs_cout % 4 || !p.xs_out.p || p.act0 != ACT_NONE ||
+            p.lgTW != 4 || p.lgTH != 3 || ((unsigned long long)p.res.p & 15ull) || ((p.res.sN | p.res.sH | p.res.sW) & 7) || ((unsigned long long)p.xs_w & 15ull) ||
+            ((unsigned long long)p.xs_out.p & 7ull) || ((p.xs_out.sN | p.xs_out.sH | p.xs_out.sW) & 3) ||
+            (p.xs_res.p && (((unsigned long long)p.xs_res.p & 7ull) || ((p.xs_res.sN | p.xs_res.sH | p.xs_res.sW) & 3)))) {
+            cs_set_error("conv_halo: xs_w (conv_s inside the spmul epilogue) needs the 128 x 256 tile kernel, 256 modulated channels, no out0, at most 64 shortcut channels");
             return -1;
         }
     }

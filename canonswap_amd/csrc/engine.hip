@@ -903,6 +903,16 @@ int spade_shortcut(cs_engine* e, const cs_engine::SpadeBlk& K, const half_t* act
     ng.p.spmul = 1;
     ng.p.res = nhwc((void*)x, S / 2, S / 2, K.fin); ng.p.res_f32 = 0; ng.p.res_shift = 1;   // nn.Upsample(x2) folded into the addressing
     ng.p.stats = stats;
+    // up_1 (256 -> 64 channels): one 128 x 256 tile holds every channel of h for its positions, conv_s runs inside that epilogue and h is never
+    // stored (ConvParams::xs_w, conv_halo_kernel.h XSK; CANONSWAP_SHORTCUT_FUSE=0: three launches)
+    static const bool fuse = [] { const char* s = getenv("CANONSWAP_SHORTCUT_FUSE"); return !s || atoi(s) != 0; }();
+    if (fuse && K.fin == 256 && K.fout <= 64 && K.cs.Cout_pad == 64 && pick_halo_cfg(ng.p, MODE_STD) == CFG_H_128x256) {
+        ng.p.xs_w = K.cs.w; ng.p.xs_cout = K.fout;
+        ng.p.xs_res = nhwc(e->g_bs, S, S, K.fout); ng.p.xs_out = nhwc(xs, S, S, K.fout);
+        ng.macs_per_pos += K.cs.macs_per_pos;
+        e->flops_exec += 2.0 * (double)B * S * S * K.fin * 64.0;
+        return go(e, ng, st);
+    }
     ng.p.out0 = nhwc(h, S, S, K.fin);
     TRY(go(e, ng, st));
     ConvCall cs = mk(K.cs, h, nhwc(nullptr, S, S, K.fin), B, 1, S, S);

@@ -259,3 +259,39 @@ def test_empty_ragged_and_mistyped_inputs(swapper, case):
     a = swapper.extract_feature_3d(img)
     b = swapper.extract_feature_3d(img.double())                                     # other float types are cast, same result
     assert torch.equal(a, b)
+
+
+_SHORTCUT_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from canonswap_amd import synth
+from canonswap_amd.can_swap_e2e import can_swapper
+sd = synth.to_torch(synth.make_state_dicts(0))
+sw = can_swapper(None, state_dicts=sd, max_batch=2)
+r = np.random.default_rng(5)
+f = torch.from_numpy(r.standard_normal((2, 32, 16, 64, 64)).astype(np.float32)).cuda()
+occ = torch.from_numpy(r.random((2, 1, 64, 64)).astype(np.float32)).cuda()
+img = sw.conv_decode(f, occ)
+np.save({out!r}, img.cpu().numpy())
+"""
+
+
+def test_learned_shortcut_forms_agree(tmp_path):
+    """G's learned shortcuts (util.py:329-344) in three forms: the reference's order (fused gamma/beta launch, then conv_s), conv_s(beta)
+    composed into one conv at load time (three launches), and - for up_1 - conv_s inside the gamma conv's epilogue.  Same image to far inside
+    the tolerance; each form is chosen once per process (environment), hence the subprocesses."""
+    import os
+    import subprocess
+    import sys
+    from oracle import canonswap_ref as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    imgs = []
+    for i, env in enumerate(({"CANONSWAP_SHORTCUT_ALGEBRA": "0"}, {"CANONSWAP_SHORTCUT_FUSE": "0"}, {})):
+        out = str(tmp_path / f"img{i}.npy")
+        subprocess.run([sys.executable, "-c", _SHORTCUT_SCRIPT.format(root=root, out=out)], check=True, env={**os.environ, **env}, timeout=600)
+        imgs.append(torch.from_numpy(np.load(out)))
+    assert imgs[0].shape == (2, 3, 512, 512)
+    for a in imgs[1:]:
+        assert O.psnr(a, imgs[0]) > 65.0
+    assert not torch.equal(imgs[1], imgs[2]) or True        # (another summation order of conv_s: equal bits are not required)
+    assert O.psnr(imgs[2], imgs[1]) > 70.0
