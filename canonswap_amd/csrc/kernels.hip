@@ -1049,7 +1049,9 @@ __global__ void __launch_bounds__(256, 2) t_mask_rows_kernel(const half_t* __res
 int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, float* tmask, int N, int H, int W, hipStream_t st)
 {
     // (which kernel runs depends on the map's shape only, never on N: a sample's bits do not depend on the batch it is in)
-    static const int rows_on = [] { const char* s = getenv("CANONSWAP_TMASK_ROWS"); return s ? atoi(s) : 8; }();
+    // Off by default: 86 -> 75 us per 64-frame launch (+0.13 % on the step), but one frame alone is 32 waves on this kernel against 256 on
+    // t_mask_kernel: +0.23 ms (3.7 %) on the single-frame step (profiles/r04_z_lat_knobs.txt) - and the choice cannot depend on N.
+    static const int rows_on = [] { const char* s = getenv("CANONSWAP_TMASK_ROWS"); return s ? atoi(s) : 0; }();
     if (rows_on && H % 8 == 0 && W % 16 == 0 && ((H / 8) * (W / 16)) % 4 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)wpacked & 15)) {
         const long items = (long)N * (H / (rows_on == 4 ? 4 : 8)) * (W / 16);
         if (rows_on == 4) hipLaunchKernelGGL(t_mask_rows_kernel<4>, dim3((unsigned)(items / 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
