@@ -41,6 +41,16 @@ def _free_port():
     return p
 
 
+def _flush_c_stdio():
+    """librccl prints a version banner through C stdio; on a redirected stdout it would sit in libc's buffer until exit and land BEHIND
+    the JSON line.  Flushing after the communicators exist keeps the JSON line the last line of rank 0's output."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +74,9 @@ def parse_args():
                     help="this many source identities resident at once, frame g of the job using identity g mod n")
     ap.add_argument("--dump-crc", default="", help="the leader of stream s writes the CRC32 of every gathered frame of the last step "
                                                    "to this path (stream 0) / path.s<s> (tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 through the multi-GPU code: RCCL communicator on a world of one, identity broadcast, chunked asynchronous "
+                         "device gather of the uint8 frames inside the timed region, sub-communicators for --streams (VERDICT r4 item 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: dry run of the multi-rank flow with all ranks sharing GPU 0 and host-side collectives (test only)")
     return ap.parse_args()
@@ -95,15 +108,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if share_gpu else dev        # where collectives run
-    if world > 1:
+    force = bool(a.force_dist) and world == 1               # one rank, every collective still issued
+    distd = world > 1 or force
+    if distd:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
-    ranks_seen = dist.get_world_size() if world > 1 else 1
+    ranks_seen = dist.get_world_size() if distd else 1
     devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(dev)}"]
-    if world > 1:
+    if distd:
         got = [None] * world
         dist.all_gather_object(got, devices[0])
         devices = got
@@ -115,24 +132,33 @@ def main():
     k = len(mine)
     if k < 1 or B % k:
         raise SystemExit(f"--batch {B} must be a multiple of the {k} streams a rank hosts")
-    comms = [None] * S if (world == 1 or S == 1) else parallel.make_stream_comms(groups)      # S == 1: the default group
+    if not distd or (S == 1 and not force):
+        comms = [None] * S                                   # S == 1: the default group
+    else:
+        comms = parallel.make_stream_comms(groups, min_ranks=1 if force else 2)
+        for c in comms:                                      # a sub-communicator that cannot form fails here, not in the timed region
+            if c is not None:
+                dist.barrier(group=c)
     # random-init weights of the real architecture.  The load-time transform (synthesis + pack.build_blobs: tens of seconds of host work,
     # 0.5 GB of packed blobs) runs on rank 0 only; the other ranks of the node read its result from /dev/shm.
     from canonswap_amd import pack
     sds, blobs = None, None
-    shm = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"canonswap_blobs_{os.environ.get('MASTER_PORT', os.getpid())}.npz")
-    if rank == 0:
+    # The packer is the first local rank of each node and the file name carries the node's name: /dev/shm is node-local.
+    shm = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                       f"canonswap_blobs_{socket.gethostname()}_{os.environ.get('MASTER_PORT', os.getpid())}.npz")
+    packer = (rank == 0) if share_gpu else (local_rank == 0)
+    if packer:
         sds = synth.to_torch(synth.make_state_dicts(0))
         blobs = pack.build_blobs(sds)
         if world > 1:
             np.savez(shm, **blobs)
     if world > 1:
         dist.barrier()
-        if rank != 0:
+        if not packer:
             with np.load(shm) as z:
                 blobs = {k: z[k] for k in z.files}
         dist.barrier()
-        if rank == 0:
+        if packer:
             os.remove(shm)
     sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), packed_blobs=blobs, max_batch=B,
                      latency_mode=a.latency_mode)
@@ -142,7 +168,7 @@ def main():
     # one-time broadcast of the source identities (2 KB each); every rank derives T's modulated weights locally
     nid = S if a.streams else max(1, min(a.identities, 8))
     sid = torch.from_numpy(synth.make_identity(7, n=nid)).to(cdev) if rank == 0 else torch.zeros(nid, 512, device=cdev)
-    parallel.broadcast_identity(sid, src=0)
+    parallel.broadcast_identity(sid, src=0, single_rank=force)
     sid = sid.to(dev)
     if a.streams:
         for s, _, slot in mine:                              # one identity slot per hosted stream
@@ -189,12 +215,12 @@ def main():
     fixed_T = 0 if (a.frames > 0 or a.streams or a.no_fixed_job) else (1200 if world > 1 else 300)      # configs[3] / configs[2]
     fplan = Plan(fixed_T) if fixed_T else None
     out_u8 = torch.empty(max(plan.n_local, fplan.n_local if fplan else 0, 1), 512, 512, 3, dtype=torch.uint8, device=dev)
-    gather_on = world > 1 and k == 1 and len(groups[mine[0][0]]) > 1
+    gather_on = distd and k == 1 and (len(groups[mine[0][0]]) > 1 or force)
     my_comm = comms[mine[0][0]]
     if gather_on:                                            # receive buffers (943 MB on the leader for 1200 frames) allocated once, here
         for pl in (plan, fplan):
             if pl is not None:
-                pl.gather = parallel.ChunkedFrameGather(pl.per_stream, pl.chunk, device=cdev, group=my_comm)
+                pl.gather = parallel.ChunkedFrameGather(pl.per_stream, pl.chunk, device=cdev, group=my_comm, single_rank=force)
 
     def step(pl, i, gather=None, out_f32=None):
         """One step: this rank's frames in chunks of B; finished chunks go to the stream's leader asynchronously."""
@@ -209,7 +235,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distd:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -228,7 +254,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         per_rank = [dt]
-        if world > 1:
+        if distd:
             t = torch.tensor([dt], dtype=torch.float64, device=cdev)
             allt = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
@@ -238,6 +264,7 @@ def main():
     for i in range(Wm):
         step(plan, i)
     dt, per_rank, gathered = timed(plan, K)
+    _flush_c_stdio()
     if a.dump_crc:                                            # tests: CRC32 of every frame of the last step, per stream, on its leader
         import zlib
         for h, (s, q, _) in enumerate(mine):
@@ -274,7 +301,7 @@ def main():
         for i in range(K):
             step(plan, i)
         prof = eng.profile_end()
-    if world > 1:
+    if distd:
         dist.barrier()
 
     cpu, parity = None, None
@@ -349,7 +376,8 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "ranks_seen": ranks_seen, "devices": devices, "per_rank_seconds": [round(x, 4) for x in per_rank],
+            "ranks_seen": ranks_seen, "backend": (a.backend if distd else None), "collectives": ("broadcast + chunked async gather" + (
+                " on a one-rank communicator (--force-dist)" if force else "")) if distd else None, "devices": devices, "per_rank_seconds": [round(x, 4) for x in per_rank],
             "config": {"workload": wl + " (256x256 crops in, random-init weights of the real architecture)",
                        "frames_per_step": plan.per_stream * S, "frames_per_launch_per_gpu": B, "frames_total": frames,
                        "parallelism": f"frame-shard x{world}" + (f", {S} streams" if a.streams else ""), "identities_resident": nid,
@@ -388,9 +416,11 @@ def main():
                 ts = max(per_rank[r] for r in g)
                 per.append({"stream": s, "ranks": g, "frames": K * plan.per_stream, "value": round(K * plan.per_stream / ts, 3), "unit": "frames/s"})
             line["streams"] = per
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distd:
         dist.destroy_process_group()
+    _flush_c_stdio()
     if rank == 0 and parity and not parity["psnr_db_min"] >= 50.0:
         raise SystemExit(f"bench: parity below the 50 dB gate (psnr_db_min {parity['psnr_db_min']})")
 

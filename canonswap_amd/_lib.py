@@ -194,7 +194,7 @@ def _isa_check_ring(obj_dir: str, objdump: str, oname: str, name_re: str, expect
     seen = {}
     for m in re.finditer(r"^[0-9a-f]+ <(" + name_re + r")>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
-        writer, waited, nmfma = {}, {}, 0
+        writer, waited, issued, nmfma = {}, {}, {}, 0      # issued[r]: VMEM ops issued before the load that last wrote v<r>
         pending, nvm = [], 0          # ring loads in flight: (destination registers, VMEM ops issued before it); VMEM ops issued so far
         mf = [i for i, l in enumerate(body) if "v_mfma" in l]
         lo, hi = (mf[0], mf[-1]) if mf else (0, 0)      # the in-flight check follows the K loop and what lies behind it up to the drain (straight-line there)
@@ -204,9 +204,10 @@ def _isa_check_ring(obj_dir: str, objdump: str, oname: str, name_re: str, expect
                 continue
             op = t.split()[0]
             if op.startswith("s_waitcnt") and "vmcnt" in t:
-                for r in waited:
-                    waited[r] = True
                 n = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                for r in waited:          # vmcnt(n) leaves at most the n youngest VMEM ops outstanding: a load is covered only if it is older
+                    if nvm - issued.get(r, -1) - 1 >= n:
+                        waited[r] = True
                 pending = [q for q in pending if nvm - q[1] - 1 < n]          # at most n VMEM ops are outstanding: the older ones have landed
             # a load the compiler does not track writes its registers when the data lands, not where the instruction stands: nothing else may
             # write them before a counted wait covers the load (the bug this guards against: a fetch whose result nobody reads looks dead to the
@@ -243,9 +244,11 @@ def _isa_check_ring(obj_dir: str, objdump: str, oname: str, name_re: str, expect
             mm = re.match(r"\S+\s+(v\[(\d+):(\d+)\]|v(\d+))", t)
             if mm and not op.startswith(("global_store", "buffer_store", "ds_write", "scratch_store")) and not (op.startswith("buffer_load") and t.endswith("lds")):
                 rng = range(int(mm.group(2)), int(mm.group(3)) + 1) if mm.group(2) else [int(mm.group(4))]
+                is_vm = op.startswith(("global_load", "buffer_load", "scratch_load"))
                 for r in rng:
                     writer[r] = op
                     waited[r] = False
+                    issued[r] = (nvm - 1) if is_vm else -1      # (nvm was advanced for this load above)
         if expect_mfma is not None and nmfma != expect_mfma:
             raise RuntimeError(f"isa_check: {name}: {nmfma} MFMAs in the kernel, expected {expect_mfma}")
         seen[name] = nmfma

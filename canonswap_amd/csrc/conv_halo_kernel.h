@@ -1206,6 +1206,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     }
     kp.persist_total = 0;
     if (SK && lds < (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float)) lds = (size_t)4 * WCH * WPX * 4 * 64 * sizeof(float);
+    if (p.xs_w && lds < (size_t)32768) lds = 32768;        // the fused-shortcut epilogue's part[2][4][4][64] float4 lives in the halo LDS
     if (lds > 160 * 1024) { cs_set_error("conv_halo: halo of %ld voxels does not fit LDS", HV); return -1; }
     dim3 grid((unsigned)(p.nTW * p.nTH * p.nTD * p.nTN), (unsigned)(p.Cout_pad / BN));
     if (p.hilo && (ST == 0 || CK != 32 || nck != 3 || db || p.sk_out)) {

@@ -348,11 +348,9 @@ int launch_wide_inst(const ConvParams& p, const WideSched& s, int grid, hipStrea
 {
     auto k = conv_wide_kernel<MODE, EPC>;
     const size_t lds = 2 * (size_t)W_BSTRIDE;
-    static bool attr_done = false;                   // per instantiation
-    if (!attr_done) {
+    {   // per launch: the attribute belongs to the current device, and engines may live on several GPUs of one process
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cs_set_error("conv_wide: opting into %zu bytes of LDS failed: %s", lds, hipGetErrorString(e)); return -1; }
-        attr_done = true;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, p, s);
     hipError_t e = hipGetLastError();

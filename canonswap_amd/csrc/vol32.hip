@@ -584,7 +584,7 @@ bool vol32_supported(const ConvParams& p)
         if (p.xf_res.p && (p.xf_kind != 2 || p.xf_res.sD != 32)) return false;
         if (p.xf_out.p && (p.xf_kind != 2 || p.xf_out.sD != 32)) return false;
     } else if (p.hilo ? (p.Cin != 96 || p.in_sD != 64) : (p.Cin != 32 || p.in_sD != 32)) return false;
-    if (p.up_shift || p.cg || p.wslot || p.sk_out || p.ragged || p.pixscale || p.stats) return false;
+    if (p.up_shift || p.cg || p.wslot || p.sk_out || p.ragged || p.pixscale || p.stats || p.pool_hw || p.spmul) return false;
     if (p.act0 > ACT_LRELU || p.act1 > ACT_LRELU) return false;
     if (p.res.p && (!p.res_f32 || p.res.sD != 32)) return false;
     if (p.out0.p && p.out0.sD != 32) return false;

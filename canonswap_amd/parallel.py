@@ -19,9 +19,10 @@ def shard_range(n_frames: int, rank: int, world: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def broadcast_identity(source_id: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
-    """One-time broadcast of the 512-float identity embedding from (global) rank `src` (in place), over `group` if given."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def broadcast_identity(source_id: torch.Tensor, src: int = 0, group=None, single_rank: bool = False) -> torch.Tensor:
+    """One-time broadcast of the 512-float identity embedding from (global) rank `src` (in place), over `group` if given.
+    single_rank: issue the collective on a one-rank communicator too (bench.py --force-dist: the RCCL call path at N = 1)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank):
         dist.broadcast(source_id, src=src, group=group)
     return source_id
 
@@ -54,12 +55,13 @@ def streams_of_rank(groups, rank: int):
     return [(s, groups[s].index(rank), k) for k, s in enumerate(mine)]
 
 
-def make_stream_comms(groups):
+def make_stream_comms(groups, min_ranks: int = 2):
     """One sub-communicator per multi-rank stream (every rank must call this with the same `groups`: dist.new_group is
-    collective over the default group).  Entry s is None for single-rank streams or without an initialised process group."""
+    collective over the default group).  Entry s is None for streams with fewer than `min_ranks` ranks (default: single-rank
+    streams need no communicator; bench.py --force-dist passes 1) or without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()):
         return [None] * len(groups)
-    return [dist.new_group(ranks=g) if len(g) > 1 else None for g in groups]
+    return [dist.new_group(ranks=g) if len(g) >= min_ranks else None for g in groups]
 
 
 def gather_frames(local: torch.Tensor, n_frames: int, dst: int = 0):
@@ -102,11 +104,17 @@ class ChunkedFrameGather:
     chunks (1200 frames over 8 ranks in chunks of 50) the chunks land directly in frame order - finish() returns a view, no copy.
 
     n_frames: total frames of the job, sharded by shard_range(); chunk: frames per collective (equal_chunks() of the largest share).
+
+    Aliasing: on the exact path finish() returns a VIEW of the persistent receive buffer; the next pass (reset() + push()) overwrites
+    it in place.  A caller that keeps the frames of pass i beyond the start of pass i + 1 asks for finish(copy=True); the ragged path
+    always returns a fresh tensor.
     """
 
-    def __init__(self, n_frames: int, chunk: int, frame_shape=(512, 512, 3), device="cpu", dst: int = 0, group=None):
-        """group: sub-communicator of one stream (stream_groups / make_stream_comms); `dst` is then the rank INSIDE the group."""
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    def __init__(self, n_frames: int, chunk: int, frame_shape=(512, 512, 3), device="cpu", dst: int = 0, group=None,
+                 single_rank: bool = False):
+        """group: sub-communicator of one stream (stream_groups / make_stream_comms); `dst` is then the rank INSIDE the group.
+        single_rank: run the collectives on a one-rank communicator as well (bench.py --force-dist)."""
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank)
         self.group = group
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
@@ -147,8 +155,9 @@ class ChunkedFrameGather:
         pieces = [self.buf[r, c * self.chunk:(c + 1) * self.chunk] for r in range(self.world)] if self.rank == self.dst else None
         self.works.append((dist.gather(pad.contiguous(), pieces, dst=self.dst_global, group=self.group, async_op=True), pad))
 
-    def finish(self):
-        """Wait for every chunk (ranks that ran out of frames push empty chunks first). Frames in order on dst, else None."""
+    def finish(self, copy: bool = False):
+        """Wait for every chunk (ranks that ran out of frames push empty chunks first). Frames in order on dst, else None.
+        copy=False: on the exact path the result aliases the receive buffer and is valid until the next pass's first push()."""
         while self.on and self.pushed < self.nchunks:
             self.push(self.pad[:0])
         for w, _ in self.works:
@@ -159,5 +168,6 @@ class ChunkedFrameGather:
         if self.rank != self.dst:
             return None
         if self.exact:
-            return self.buf.view((self.world * self.nchunks * self.chunk,) + self.frame_shape)
+            v = self.buf.view((self.world * self.nchunks * self.chunk,) + self.frame_shape)
+            return v.clone() if copy else v
         return torch.cat([self.buf[r, : b - a] for r, (a, b) in enumerate(self.counts)], 0)

@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the test suite wants the whole build: a missing llvm-objdump (isa_check skipped) or test library is an error here, not a printed note
+os.environ.setdefault("CANONSWAP_STRICT_BUILD", "1")
 
 
 def pytest_configure(config):

@@ -21,6 +21,7 @@ def _run(cmd):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]           # ONE JSON line, from rank 0
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0], r.stdout[-600:]      # ... and the last one (librccl's banner comes before it)
     return json.loads(lines[0])
 
 
@@ -66,3 +67,33 @@ def test_streams_on_rank_pairs_equal_streams_hosted_on_one_rank(tmp_path):
         a, b = json.load(open(f"{c1}.s{s}")), json.load(open(f"{c4}.s{s}"))
         assert len(a) == 6 and a == b, s
     assert json.load(open(f"{c1}.s0")) != json.load(open(f"{c1}.s1"))
+
+
+def test_rccl_world_of_one_runs_every_collective_and_equals_the_plain_run(tmp_path):
+    """the nccl (= RCCL) branch of bench.py on the one GPU a box has.  --force-dist forms the communicator with
+    device_id, broadcasts the identity, builds ChunkedFrameGather on the DEVICE and pushes the real out_u8 chunks through asynchronous
+    dist.gather inside the timed region (ragged: 18 frames in chunks of 4 -> the padded last chunk and the torch.cat path; exact:
+    16 frames -> the view path).  Same bytes per frame as the run without a process group."""
+    for frames in (18, 16):
+        common = ["--frames", str(frames), "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+        crc1, crc2 = str(tmp_path / f"plain{frames}.json"), str(tmp_path / f"rccl{frames}.json")
+        one = _run([sys.executable, "bench.py", "--gpus", "1", *common, "--dump-crc", crc1])
+        two = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", *common, "--dump-crc", crc2])
+        assert one["ranks_seen"] == 1 and one["backend"] is None
+        assert two["ranks_seen"] == 1 and two["backend"] == "nccl" and "gather" in two["collectives"]
+        a, b = json.load(open(crc1)), json.load(open(crc2))
+        assert len(a) == frames and a == b
+
+
+def test_rccl_world_of_one_weak_scaling_line_and_stream_subcommunicators(tmp_path):
+    """The default (weak-scaling) line with its fixed-size job through RCCL at N = 1, and --streams 2 with dist.new_group sub-communicators
+    (one per stream, formed and barriered on the device) against the same streams without a process group."""
+    line = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert line["backend"] == "nccl" and line["scaling"] == "weak" and line["fixed_job"]["frames"] == 300 and line["value"] > 0
+    common = ["--streams", "2", "--frames", "6", "--batch", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    c1, c2 = str(tmp_path / "plain"), str(tmp_path / "rccl")
+    _run([sys.executable, "bench.py", "--gpus", "1", *common, "--dump-crc", c1])
+    two = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", *common, "--dump-crc", c2])
+    assert two["backend"] == "nccl"
+    for s in range(2):
+        assert json.load(open(f"{c1}.s{s}")) == json.load(open(f"{c2}.s{s}"))

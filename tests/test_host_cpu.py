@@ -74,6 +74,45 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.cs_abi_version() == _lib.ABI_VERSION == 3
 
 
+def test_isa_check_of_the_hand_counted_weight_rings():
+    """The objects the shipped library was linked from (canonswap_amd/build/): every untracked ring load is covered by a counted wait that
+    is deep enough for it before an MFMA reads it (the check marks a register waited only when its load is older than the
+    N youngest VMEM ops of `s_waitcnt vmcnt(N)`)."""
+    from canonswap_amd import _lib
+    if not os.path.isdir(_lib.OBJ_DIR) or not os.path.exists(os.path.join(_lib.OBJ_DIR, "conv_wide.o")):
+        pytest.skip("no object files next to the library (prebuilt .so only)")
+    seen = _lib.isa_check()
+    assert len(seen) >= 70 and any("conv_wide_kernel" in k for k in seen)
+
+
+def test_isa_check_rejects_a_wait_that_is_too_shallow(tmp_path, monkeypatch):
+    """A counted wait whose immediate leaves the consumed load among the outstanding ones must fail the check."""
+    from canonswap_amd import _lib
+    asm = """0000000000001000 <conv_wide_kernel_fake>:
+	global_load_dwordx4 v[10:13], v[0:1], off
+	global_load_dwordx4 v[14:17], v[0:1], off
+	s_waitcnt vmcnt(%d)
+	v_mfma_f32_16x16x32_f16 a[0:3], v[10:13], v[20:23], a[0:3]
+	v_mfma_f32_16x16x32_f16 a[0:3], v[14:17], v[20:23], a[0:3]
+	s_endpgm
+"""
+    import subprocess as sp
+
+    def fake_run_factory(n):
+        def fake_run(cmd, **kw):
+            class R:
+                stdout = asm % n
+            return R()
+        return fake_run
+
+    (tmp_path / "fake.o").write_bytes(b"")
+    monkeypatch.setattr(_lib.subprocess, "run", fake_run_factory(0))
+    assert _lib._isa_check_ring(str(tmp_path), "objdump", "fake.o", r"conv_wide_kernel_fake", 2) == {"conv_wide_kernel_fake": 2}
+    monkeypatch.setattr(_lib.subprocess, "run", fake_run_factory(1))       # vmcnt(1): the second load may still be in flight
+    with pytest.raises(RuntimeError, match="no vmcnt wait"):
+        _lib._isa_check_ring(str(tmp_path), "objdump", "fake.o", r"conv_wide_kernel_fake", 2)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_engine_fails_loudly_without_gpu():
     from canonswap_amd.engine import Engine

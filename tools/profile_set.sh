@@ -12,4 +12,4 @@ CANONSWAP_LIB=ab/timeline.so python tools/timeline.py --out gpurun_out/${TAG}/ti
 python bench.py --no-cpu-baseline --batch 1 --steps 50 --warmup 10 2>/dev/null | tail -1 > gpurun_out/${TAG}/bench_b1.json
 python bench.py --no-cpu-baseline --batch 1 --latency-mode --steps 50 --warmup 10 2>/dev/null | tail -1 > gpurun_out/${TAG}/bench_b1_latency_mode.json
 CANONSWAP_PROFILE_CSV=/root/repo/gpurun_out/${TAG}/layers_b1_latency_mode.csv python bench.py --no-cpu-baseline --batch 1 --latency-mode --steps 1 --warmup 2 > /dev/null 2>&1
-python bench.py --no-cpu-baseline --fp8-weights --identities 4 2>/dev/null | tail -1 > gpurun_out/${TAG}/bench_fp8_4identities.json
+python bench.py --no-cpu-baseline --identities 4 2>/dev/null | tail -1 > gpurun_out/${TAG}/bench_4identities.json
