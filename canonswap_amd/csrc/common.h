@@ -109,7 +109,7 @@ struct ConvParams {
     // and stores 8 logit vectors per tile row: kw_out[((n * D + d) * H + h) * (W / 2) + tile][j][22], j <-> output column w0 - 3 + j
     // (dense_motion.py:88: logit(w) = sum_kw part[w + kw - 3][kw]).  45 % fewer bytes on both sides of the hand-over to the softmax.
     float* kw_out;
-    // tests / A/B (CANONSWAP_EP_GENERAL=1): run the general epilogue where the kernel also carries branch-free copies (conv_epilogue.h)
+    // tests (cs_conv_desc::ep_general): run the general epilogue where the kernel also carries branch-free copies (conv_epilogue.h)
     int ep_general;
     // conv_halo, 3-D tiles of 8 or 4 columns, fp16 out0 only: out0 = AvgPool(1,2,2) of act0(conv + bias) computed in the epilogue (DownBlock3d,
     // util.py:185-190); out0's strides address the POOLED grid (h / 2, w / 2).  The average is taken over the fp32 values: one rounding.

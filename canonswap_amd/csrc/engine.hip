@@ -100,7 +100,7 @@ struct cs_engine {
     float *se_a = nullptr, *se_b = nullptr, *se_part = nullptr; size_t se_cap = 0;
 
     // ---- workspace
-    half_t *f_t0, *f_t1, *f_p0, *f_t2, *f_p1;
+    half_t *f_t0, *f_p0, *f_p1;
     float* vs[3]; half_t* va[2];
     float* sk_buf = nullptr; size_t sk_cap = 0;      // split-K partial sums (floats)
     half_t* vsp[2];                        // split-precision conv inputs of R's GroupNorm blocks: [hi | lo] per voxel
@@ -252,24 +252,14 @@ void set_tile(ConvParams& p, int BM, int prefW, int prefH)
 // tiles measured slower (more halo re-reads than the extra occupancy returns)
 int cfg_v32() { return CFG_H_256x32; }
 
-// 256-position tiles of the hourglass tail / mask conv (160 channels) and the first encoder block (64 channels); with them the
-// ragged last chunk of those layers (Cin 144 / 112) runs paired taps (CANONSWAP_RAGGED=0: A/B knob)
-bool big160() { static const bool v = [] { const char* s = getenv("CANONSWAP_TILE256x160"); return s ? atoi(s) != 0 : true; }(); return v; }
-bool enc256() { static const bool v = [] { const char* s = getenv("CANONSWAP_ENC256"); return s ? atoi(s) != 0 : true; }(); return v; }
+// The hourglass tail / mask conv (160 packed channels) and the first encoder block (64 channels) run 256-position tiles; the ragged last
+// chunk of those layers (Cin 144 / 112) runs paired taps.  (The A/B knobs of rounds 1-4 that selected the older forms are gone:
+// profiles/HISTORY.md section 6 keeps their records.)
 // SPADE gamma/beta convs with 128 or more modulated channels (Cout_pad % 256 == 0) on 128x256 tiles from three frames up: +0.5 % with the
 // conflict-free LDS image (neutral before it).  Those layers keep 64-channel chunks at every batch size (same K order, same bits); the
 // 64-channel ones (Cout_pad 128) run 32-channel chunks on 128x128 tiles.
-bool spade256() { static const bool v = [] { const char* s = getenv("CANONSWAP_SPADE256"); return !s || atoi(s) != 0; }(); return v; }
-bool ragged_on() { static const bool v = [] { const char* s = getenv("CANONSWAP_RAGGED"); return s ? atoi(s) != 0 : true; }(); return v; }
-
-// ConvParams::persist_total request of every engine launch (A/B knob CANONSWAP_HALO_PERSIST=0|1)
-int halo_persist_default() { static const int v = [] { const char* s = getenv("CANONSWAP_HALO_PERSIST"); return s ? atoi(s) : 1; }(); return v; }
-// ConvParams::xcd_map of every engine launch (A/B knob CANONSWAP_XCD_MAP=0|1|2)
-int xcd_map_default()
-{
-    static const int v = [] { const char* s = getenv("CANONSWAP_XCD_MAP"); return s ? atoi(s) : 2; }();   // 2: +0.8 % on the step (r02 A/B)
-    return v;
-}
+constexpr int HALO_PERSIST = 1;        // ConvParams::persist_total request of every engine launch (persistent tile walk where the kernel has one)
+constexpr int XCD_MAP = 2;             // ConvParams::xcd_map of every engine launch (+0.8 % on the step over the plain order, r02 A/B)
 
 int pick_halo_cfg(const ConvParams& p, int mode)
 {
@@ -284,25 +274,22 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     // ... and, since the round-2 epilogue / addressing work, for the other 3x3 convs with 256 or more output channels (G 512->512 with
     // and without statistics, R's 512-channel pair, W.third): +0.7 % on the step, the same per-64-position statistics, the same bits
     // (CANONSWAP_G256=0: the 128x128 tiles; 1: only the convs without statistics)
-    static const int g256 = [] { const char* s = getenv("CANONSWAP_G256"); return s ? atoi(s) : 2; }();
-    if (spade256() && mode == MODE_SPADE && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 &&
+    if (mode == MODE_SPADE && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 &&
         (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
-    if (g256 && (mode == MODE_STD || (g256 > 1 && mode == MODE_STDSTAT)) && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 &&
+    if ((mode == MODE_STD || mode == MODE_STDSTAT) && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 &&
         p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 && (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     if (Cout_pad % 128 == 0) {
         // a launch of 128 or fewer 128x128 workgroups leaves half of the 256 CUs idle (one frame: the 512-channel 3x3 convs at 64x64
         // are 32 x 4): 128x64 tiles put a workgroup on every CU.  Same K order per output element, same bits.
-        static const bool narrow = [] { const char* s = getenv("CANONSWAP_NARROW"); return !s || atoi(s) != 0; }();
         const long tiles = ((long)p.N * p.D * p.H * p.W + 127) / 128;
-        if (narrow && (mode == MODE_STD || mode == MODE_STDSTAT) && p.KH == 3 && p.KW == 3 && tiles * (Cout_pad / 128) <= 128)
+        if ((mode == MODE_STD || mode == MODE_STDSTAT) && p.KH == 3 && p.KW == 3 && tiles * (Cout_pad / 128) <= 128)
             return CFG_H_128x64;
         return CFG_H_128x128;
     }
     // 64 output channels at 128x128 or more (G's last up block, F's first down block): 256-position tiles (16x16), two position waves x two
     // channel waves - a wave tile of 128 positions halves the weight bytes per MFMA of the 128x64 tile's 64-position wave tiles
-    // (CANONSWAP_UP256=0: A/B knob).  Same K order per output element; statistics per 16 x 4 positions as on every tile.
-    static const bool up256 = [] { const char* s = getenv("CANONSWAP_UP256"); return !s || atoi(s) != 0; }();
-    if (up256 && Cout_pad == 64 && (mode == MODE_STD || mode == MODE_STDSTAT) && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.Cin % 64 == 0 && p.cg == 0 &&
+    // Same K order per output element; statistics per 16 x 4 positions as on every tile.
+    if (Cout_pad == 64 && (mode == MODE_STD || mode == MODE_STDSTAT) && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.Cin % 64 == 0 && p.cg == 0 &&
         p.H % 16 == 0 && p.W % 16 == 0 && p.H >= 128 && !p.sk_out) return CFG_H_256x64;
     if (Cout_pad % 64 == 0) return CFG_H_128x64;
     if (Cout_pad % 32 == 0) return CFG_H_128x32;
@@ -311,6 +298,7 @@ int pick_halo_cfg(const ConvParams& p, int mode)
 
 int amax_after(cs_engine* e, const struct ConvCall& c, hipStream_t st);
 
+constexpr int VOL32_MINB = 3;          // below three frames the plain volume convs stay on the halo kernel (see go())
 bool vol32_enabled() { static const bool on = [] { const char* s = getenv("CANONSWAP_VOL32"); return !s || atoi(s) != 0; }(); return on; }
 // GroupNorm apply / hi-lo split of R's stage-3 blocks inside the consumer conv's staging (vol32 transform staging) instead of stand-alone
 // norm_act / split16 passes (CANONSWAP_VOL32_XF=0: A/B knob)
@@ -334,8 +322,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     // (below three frames the strips of a launch cover a quarter of the CUs or less: the plain convs - bit-identical on either kernel - stay
     // on the halo kernel there, one frame 6.75 -> 6.5 ms; the statistics / transform-staging convs of R always run vol32: their partial
     // statistics are laid out per kernel, and a frame's bits must not depend on the batch it is part of)
-    static const int vol32_minb = [] { const char* s = getenv("CANONSWAP_VOL32_MINB"); return s ? atoi(s) : 3; }();
-    if (vol32_enabled() && vol32_supported(c.p) && (c.p.N >= vol32_minb || c.p.stat_out || c.p.xf_kind)) {
+    if (vol32_enabled() && vol32_supported(c.p) && (c.p.N >= VOL32_MINB || c.p.stat_out || c.p.xf_kind)) {
         c.stat_nblk = vol32_stat_nblk(c.p);
         TRY(e->run(0, st, [&] { return launch_vol32(c.p, st); }, c.name, fl));
         return amax_after(e, c, st);
@@ -348,8 +335,6 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     // (profiles/r04_c_ab_wide.txt).
     static const int wide_on = [] { const char* s = getenv("CANONSWAP_WIDE"); return s ? atoi(s) : 1; }();
     if (wide_on && !e->latency_mode && c.hcfg < 0 && (c.mode != MODE_SPADE || wide_on >= 2)) {
-        static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
-        c.p.ep_general = epg;
         if (conv_wide_supported(c.p, c.mode) && (long)c.p.N * (c.p.H / 16) * (c.p.W / 16) * (c.p.Cout_pad / 256) >= 512) {
             c.stat_nblk = (c.p.W / 16) * (c.p.H / 8) * 2;      // partial-statistics blocks per sample: 64 positions each, in the 16 x 8 tiles' order
             TRY(e->run(0, st, [&] { return launch_conv_wide(c.p, c.mode, st); }, c.name, fl));
@@ -368,15 +353,10 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             c.stat_nblk = c.p.nTW * c.p.nTH * c.p.nTD * (BM / wave_px);
         }
         // SPADE convs run 32-channel chunks: their LDS image is then conflict-free at three workgroups per CU (conv_halo_kernel.h, halo_pad)
-        static const bool spade32 = [] { const char* s = getenv("CANONSWAP_SPADE_CK32"); return !s || atoi(s) != 0; }();
-        const bool spade_ck32 = spade32 && c.mode == MODE_SPADE && !(spade256() && c.p.Cout_pad % 256 == 0);
+        const bool spade_ck32 = c.mode == MODE_SPADE && c.p.Cout_pad % 256 != 0;
         const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !spade_ck32) ? 64 : 32;
-        c.p.xcd_map = xcd_map_default();
-        c.p.persist_total = halo_persist_default();
-        {
-            static const int epg = [] { const char* s = getenv("CANONSWAP_EP_GENERAL"); return s ? atoi(s) : 0; }();
-            c.p.ep_general = epg;
-        }
+        c.p.xcd_map = XCD_MAP;
+        c.p.persist_total = HALO_PERSIST;
         {   // cross-workgroup split-K when the launch cannot fill the chip (single-frame latency: the deep hourglass levels run 8-64
             // workgroups that each stream megabytes of weights): plain bias + activation + one output only
             // Split sums are added in another order than one workgroup's sequential accumulation, so results differ in the last
@@ -390,8 +370,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
             const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
                                c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0 && !c.p.pool_hw && !c.p.spmul;
-            static const int sk_maxwg = [] { const char* s = getenv("CANONSWAP_SK_MAXWG"); return s ? atoi(s) : 64; }();   // r02 sweep
-            static const int sk_fill = [] { const char* s = getenv("CANONSWAP_SK_FILL"); return s ? atoi(s) : 512; }();
+            constexpr int sk_maxwg = 64, sk_fill = 512;      // r02 sweep
             if (sk_on && plain && wgs <= sk_maxwg && nck >= 4 && e->sk_buf) {
                 int splits = (int)(sk_fill / wgs);
                 if (splits > nck) splits = nck;
@@ -468,8 +447,7 @@ bool vol32_fused_on() { static const bool on = [] { const char* s = getenv("CANO
 int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Affine* final_post, int final_act, hipStream_t st)
 {
     // util.py:94-102; a = relu(bn1(x)) is already in va[0]; x (fp32 residual stream) in vs[*cur]
-    static const int fused_minb = [] { const char* s = getenv("CANONSWAP_VOL32_MINB"); return s ? atoi(s) : 3; }();
-    if (vol32_fused_on() && B >= fused_minb) {
+    if (vol32_fused_on() && B >= VOL32_MINB) {
         // block i reads a from va[i & 1] and leaves the next block's a in va[(i + 1) & 1] (a neighbouring workgroup still reads the halo
         // columns of the input while this one stores): six blocks end in va[0] again
         for (int i = 0; i < 6; ++i) {
@@ -514,11 +492,9 @@ int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Aff
 // [W_hi | W_lo] along the input channels (pack._pack_F) and the launch reads the same activations for both halves (grouped chunks at group
 // stride 0), so out = W_hi x + W_lo x in one fp16 MFMA conv of twice the K.  The fp16 rounding of these three weight tensors alone cost the
 // frame more than any other stage's arithmetic except T's (tests/psnr_attrib.py and the CPU emulation in DESIGN section 3: 57.5 dB with only
-// these weights rounded, everything else exact); the three launches are 0.7 ms of a 125 ms step.  CANONSWAP_F_WSPLIT=0: W_hi only (the A/B knob).
-bool f_wsplit() { static const bool v = [] { const char* s = getenv("CANONSWAP_F_WSPLIT"); return !s || atoi(s) != 0; }(); return v; }
+// these weights rounded, everything else exact); the three launches are 0.7 ms of a 125 ms step.
 static void wsplit_in(ConvCall& c, int cin_real)
 {
-    if (!f_wsplit()) return;
     c.p.cg = cin_real / 32; c.p.cg_cin = cin_real; c.p.in_sG = 0;       // chunk j -> channels (j % cg) * 32 of the one input tensor
 }
 
@@ -528,25 +504,15 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
     e->flops += 2.0 * 3 * 64 * 9 * (double)B * IMG * IMG;
     // DownBlock2d (util.py:150-165): conv3x3 + folded BN + ReLU + AvgPool2d(2); the pool runs inside the conv's epilogue (ConvParams::pool_hw:
     // the average of the four fp32 values, one rounding, no full-resolution tensor) where the kernel carries it: the 32-channel-chunk
-    // 16 x 8 tiles the [W_hi | W_lo] weights run on (CANONSWAP_POOL_FOLD=0, CANONSWAP_F_WSPLIT=0: the two-launch form)
-    static const bool pool_fold = [] { const char* s = getenv("CANONSWAP_POOL_FOLD"); return !s || atoi(s) != 0; }();
-    const bool fold = pool_fold && f_wsplit();       // (also in latency mode: these launches are 512 / 256 workgroups, never split-K)
+    // 16 x 8 tiles the [W_hi | W_lo] weights run on (also in latency mode: these launches are 512 / 256 workgroups, never split-K)
     ConvCall d0 = mk(e->f_down0, e->f_t0, nhwc(nullptr, 256, 256, 64), B, 1, 256, 256);
     d0.p.act0 = ACT_RELU; wsplit_in(d0, 64);
-    if (fold) { d0.p.pool_hw = 1; d0.p.out0 = nhwc(e->f_p0, 128, 128, 128); TRY(go(e, d0, st)); }
-    else {
-        d0.p.out0 = nhwc(e->f_t1, 256, 256, 128);
-        TRY(go(e, d0, st));
-        TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t1, B, 1, 256, 256, 128, nhwc(e->f_p0, 128, 128, 128), st); }, "avgpool"));
-    }
+    d0.p.pool_hw = 1; d0.p.out0 = nhwc(e->f_p0, 128, 128, 128);
+    TRY(go(e, d0, st));
     ConvCall d1 = mk(e->f_down1, e->f_p0, nhwc(nullptr, 128, 128, 128), B, 1, 128, 128);
     d1.p.act0 = ACT_RELU; wsplit_in(d1, 128);
-    if (fold) { d1.p.pool_hw = 1; d1.p.out0 = nhwc(e->f_p1, 64, 64, 256); TRY(go(e, d1, st)); }
-    else {
-        d1.p.out0 = nhwc(e->f_t2, 128, 128, 256);
-        TRY(go(e, d1, st));
-        TRY(e->run(1, st, [&] { return launch_avgpool(e->f_t2, B, 1, 128, 128, 256, nhwc(e->f_p1, 64, 64, 256), st); }, "avgpool"));
-    }
+    d1.p.pool_hw = 1; d1.p.out0 = nhwc(e->f_p1, 64, 64, 256);
+    TRY(go(e, d1, st));
     *cur = 0;
     ConvCall s = mk(e->f_second, e->f_p1, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);   // 1x1 -> the 32x16 volume
     s.p.out0 = hwdc2(e->vs[0]); s.p.out0_f32 = 1;
@@ -579,14 +545,12 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         (void)cin;
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_pre, FD, S, S, cout[i]);
-        if (i == 0 && enc256()) c.hcfg = CFG_H_256x64;      // 64 channels at 64x64: 256-position tiles (0.65 -> 0.47 ms per 16 frames)
+        if (i == 0) c.hcfg = CFG_H_256x64;      // 64 channels at 64x64: 256-position tiles (0.65 -> 0.47 ms per 16 frames)
         TDesc o = dhwc(e->dm_l[i + 1] + skip_off[i + 1], FD, S / 2, S / 2, lw[i + 1]);
         // AvgPool3d((1,2,2)) of the block (util.py:189) inside the conv's epilogue: the average of the four fp32 values, rounded once, goes
-        // straight into the next level's concat buffer - no full-resolution tensor, no pooling launch (CANONSWAP_POOL_FOLD=0:
-        // the two-launch form, whose average is taken over fp16-rounded values).  Latency mode keeps the two launches (its split-K convs leave
-        // partial sums).
-        static const bool pool_fold = [] { const char* s = getenv("CANONSWAP_POOL_FOLD"); return !s || atoi(s) != 0; }();
-        if (pool_fold && !e->latency_mode) {
+        // straight into the next level's concat buffer - no full-resolution tensor, no pooling launch.  Latency mode keeps
+        // the two launches (its split-K convs leave partial sums; the average is then taken over fp16-rounded values).
+        if (!e->latency_mode) {
             c.p.pool_hw = 1; c.p.out0 = o;
             TRY(go(e, c, st));
             continue;
@@ -599,8 +563,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         ConvCall c = mk(e->w_dec[i], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, S, S, 1);
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_l[lv - 1], FD, S, S, lw[lv - 1]);
-        static const bool direct = getenv("CANONSWAP_DEC_DIRECT") != nullptr;     // A/B knob: 3x3x3 conv on the up-sampled grid
-        if (i >= 3 && !direct) {
+        if (i >= 3) {
             // the nearest (1,2,2) up-sampling makes the three row / column taps read two source rows / columns: one 3x2x2 conv per
             // output phase (y, x) = (2i + a, 2j + b) on the source grid, 12 of 27 taps (pack.upsampled_conv3d_phases)
             const int lwo = lw[lv - 1];
@@ -621,25 +584,20 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     ConvCall t = mk(e->w_tail, e->dm_l[0], dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // util.py:261-263
     t.p.act0 = ACT_RELU; t.p.out0 = dhwc(e->dm_pred, FD, 64, 64, 144);
     // 160-wide tiles: 128 positions (two workgroups per CU) or 256 positions (one per CU, half the weight bytes per MFMA)
-    // (tail 1.78 -> 1.29 ms, mask 2.63 -> 2.01 ms per 16 frames, profiles/r02_timeline_*.txt; CANONSWAP_TILE256x160=0 is the A/B knob)
-    t.hcfg = big160() ? CFG_H_256x160 : CFG_H_128x160;
+    // (tail 1.78 -> 1.29 ms, mask 2.63 -> 2.01 ms per 16 frames, profiles/r02_timeline_*.txt)
+    t.hcfg = CFG_H_256x160;
     TRY(go(e, t, st));
     ConvCall m = mk(e->w_mask, e->dm_pred, dhwc(nullptr, FD, 64, 64, 144), B, FD, 64, 64);   // dense_motion.py:88
     m.p.out0 = dhwc(e->dm_logits, FD, 64, 64, 160); m.p.out0_f32 = 1;     // (kw, c) partials, finished by dm_softmax
     // ... or, on the 256-position tiles (2 x 8 x 16), summed over kw inside the tile as far as the tile reaches: 8 logit vectors per 2 columns
-    // instead of 14 (ConvParams::kw_out; CANONSWAP_MASK_KWSUM=0: A/B knob).  Another, fixed summation order of the 7 partials of a logit.
-    static const bool kwsum_on = [] { const char* s = getenv("CANONSWAP_MASK_KWSUM"); return !s || atoi(s) != 0; }();
-    static const bool wide_tile = getenv("CANONSWAP_MASK_TILE8") != nullptr;
-    // ... on 4-column tiles (4 x 8 x 8; CANONSWAP_MASK_TILE4=0: the 2-column tiles): 10 logit vectors per 4 columns instead of 8 per 2 - the
-    // hand-over to the softmax is 0.92 GB per 64-frame call instead of 1.48 GB, for 27 % more halo (784 voxels per 256 positions instead of 616)
-    static const bool tile4 = [] { const char* s = getenv("CANONSWAP_MASK_TILE4"); return !s || atoi(s) != 0; }();
-    const int compact = (kwsum_on && big160() && !wide_tile && !mask_out) ? (tile4 ? 2 : 1) : 0;
+    // instead of 14 (ConvParams::kw_out): another, fixed summation order of the 7 partials of a logit.
+    // ... on 4-column tiles (4 x 8 x 8): 10 logit vectors per 4 columns instead of 8 per 2 - the hand-over to the softmax is 0.92 GB per 64-frame
+    // call instead of 1.48 GB, for 27 % more halo (784 voxels per 256 positions instead of 616).  A caller that wants the mask itself
+    // (cs_warp's debug output) gets the plain (kw, c) partials on 2-column tiles.
+    const int compact = mask_out ? 0 : 2;
     if (compact) { m.p.kw_out = e->dm_logits; m.p.out0.p = nullptr; }
-    m.hcfg = big160() ? CFG_H_256x160 : CFG_H_128x160;
-    {   // no halo along W (KW = 1): a 2x8x8 tile stages 392 halo voxels per 128 positions, 8x8x2 would stage 896
-        static const bool wide = getenv("CANONSWAP_MASK_TILE8") != nullptr;
-        TRY(go(e, m, st, wide ? 8 : (compact == 2 ? 4 : 2), 8));
-    }
+    m.hcfg = CFG_H_256x160;
+    TRY(go(e, m, st, compact == 2 ? 4 : 2, 8));     // no halo along W (KW = 1)
     if (warp_in && !mask_out && warp_fused()) {
         TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, want_deform ? e->dm_deform : nullptr, B, FD, FH, FW, st, compact); },
                    "dm_softmax_warp"));
@@ -650,11 +608,10 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose
     // input channels are grouped by depth slice (16 groups of 144 channels at stride sD) and whose 7 output channels are the
     // 7 horizontal taps (summed by occ_finish_kernel).
-    // Batched path (CANONSWAP_OCC49=0: A/B knob): the taps move into the output channels altogether - a 1x1 conv over the same grouped
+    // Batched path: the taps move into the output channels altogether - a 1x1 conv over the same grouped
     // channels with 49 (ky, kx) output channels (64 packed), finished by occ_finish49_kernel.  The (7,1)-tap form reads every activation
     // from LDS seven times for 7 useful output rows of 32 and was bound by exactly that (0.37 ms per call at 32 frames for 604 MB).
-    static const bool occ49 = [] { const char* s = getenv("CANONSWAP_OCC49"); return !s || atoi(s) != 0; }();
-    if (occ49 && !e->latency_mode) {
+    if (!e->latency_mode) {
         ConvCall oc = mk(e->w_occ49, e->dm_pred, td(nullptr, (long)FD * 4096 * 144, 0, 64L * 144, 144), B, 1, 64, 64);
         oc.p.cg = 5; oc.p.cg_cin = 144; oc.p.in_sG = 4096L * 144;
         oc.p.out0 = nhwc(e->dm_occpart, 64, 64, 64); oc.p.out0_f32 = 1;
@@ -713,17 +670,11 @@ int run_T(cs_engine* e, int B, const int* slots, int* cur, hipStream_t st)
             TLayer& L = e->t_l[i * 2 + j];
             const half_t* in = e->va[j];
             // mask_conv + sigmoid (:118-121,176): 512 -> 1 channel, a memory-bound dot product - its own VALU kernel (t_mask_kernel: 65 -> 4x us
-            // per launch against one row of sixteen on the MFMA kernel; CANONSWAP_TMASK_VALU=0: A/B knob, another summation order)
-            static const bool tmask_valu = [] { const char* s = getenv("CANONSWAP_TMASK_VALU"); return !s || atoi(s) != 0; }();
-            if (tmask_valu) {
+            // per launch against one row of sixteen on the MFMA kernel)
+            {
                 const double mfl = 2.0 * L.mask.macs_per_pos * (double)B * 4096;
                 e->flops += mfl; e->flops_exec += mfl;
                 TRY(e->run(0, st, [&] { return launch_t_mask(in, L.mask.w, L.mask.b, e->tmask, B, 64, 64, st); }, L.mask.name.c_str(), mfl));
-            } else {
-                ConvCall mc = mk(L.mask, in, hwdc2(nullptr), B, 1, 64, 64);
-                mc.p.act0 = ACT_SIGMOID;
-                mc.p.out0 = td(e->tmask, 4096L * 4, 0, 64 * 4, 4); mc.p.out0_f32 = 1;
-                TRY(go(e, mc, st));
             }
             ConvCall fc = mk(L.fused, in, hwdc2(nullptr), B, 1, 64, 64);      // [W ; w_mod] fused, blend epilogue
             fc.mode = MODE_TBLEND;
@@ -933,16 +884,9 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     TRY(go(e, s64, st));
     // mlp_shared of the up blocks reads seg nearest-resized to 128 / 256 (util.py:297-298): run per output row phase on the 64x64
     // source grid and per group of column phases (pack.upsampled_conv_phases): 16/36 and 36/144 of the taps, same result
-    static const bool direct = getenv("CANONSWAP_SHARED_DIRECT") != nullptr;     // A/B knob: 3x3 convs on the up-sampled grid
     for (int lv = 0; lv < 2; ++lv) {
         const int sc = lv ? 4 : 2, S = 64 * sc;
         half_t* dst = lv ? e->g_a256 : e->g_a128;
-        if (direct) {
-            ConvCall c = mk(lv ? e->g_sh256 : e->g_sh128, seg, nhwc(nullptr, 64, 64, 256), B, 1, S, S, lv ? 2 : 1);
-            c.p.act0 = ACT_RELU; c.p.out0 = nhwc(dst, S, S, 384);
-            TRY(go(e, c, st));
-            continue;
-        }
         for (int k = 0; k < e->g_nshp[lv]; ++k) {
             const cs_engine::ShPhase& P = e->g_shp[lv][k];
             ConvCall c = mk(P.conv, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
@@ -1088,7 +1032,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
 {
     if (!out || max_batch < 1) { cs_set_error("cs_create: bad arguments"); return -1; }
     // the kernels keep per-tensor element offsets in 32 bits; the largest activation (B x 256 x 256 x 384) reaches 2^31 at B = 85
-    if (max_batch > 64) { cs_set_error("cs_create: max_batch %d exceeds 64 (32-bit element offsets inside one tensor)", max_batch); return -1; }
+    if (max_batch > 84) { cs_set_error("cs_create: max_batch %d exceeds 84 (32-bit element offsets inside one tensor)", max_batch); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) {
         cs_set_error("cs_create: HIP device %d not available (%d devices visible)", device_id, ndev);
@@ -1099,7 +1043,7 @@ extern "C" int cs_create(int device_id, int max_batch, cs_engine** out)
     e->dev = device_id; e->maxB = max_batch;
     const size_t B = (size_t)max_batch;
 #define A(ptr, n) if (e->alloc(&e->ptr, (size_t)(n)) != 0) { cs_destroy(e); return -1; }
-    A(f_t0, B * 65536 * 64); A(f_t1, B * 65536 * 128); A(f_p0, B * 16384 * 128); A(f_t2, B * 16384 * 256); A(f_p1, B * 4096 * 256);
+    A(f_t0, B * 65536 * 64); A(f_p0, B * 16384 * 128); A(f_p1, B * 4096 * 256);
     for (int i = 0; i < 3; ++i) A(vs[i], B * VOL);
     for (int i = 0; i < 2; ++i) A(va[i], B * VOL);
     for (int i = 0; i < 2; ++i) A(vsp[i], B * VOL * 2);
@@ -1201,7 +1145,6 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     TRY(get_conv(e, "F.down0", 128, 128, 128, 1, 3, 3, 128, 64.0 * 128 * 9, &e->f_down0));
     TRY(get_conv(e, "F.down1", 256, 256, 256, 1, 3, 3, 256, 128.0 * 256 * 9, &e->f_down1));
     TRY(get_conv(e, "F.second", 512, 512, 512, 1, 1, 1, 512, 256.0 * 512, &e->f_second));
-    if (!f_wsplit()) { e->f_down0.Cin = 64; e->f_down1.Cin = 128; e->f_second.Cin = 256; }
     TRY(get_affine(e, "F.pre0", 512, &e->f_pre0));
     for (int which = 0; which < 2; ++which) {
         cs_engine::RB3* rb = which ? e->t_rb : e->f_rb;
@@ -1229,15 +1172,15 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     }
     TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));
     TRY(get_conv(e, "W.maskp", 144, 160, 160, 7, 7, 1, 0, 142.0 * 22 * 343, &e->w_mask));
-    if (ragged_on()) {      // Cin 144 / 144 / 112: the 16 real channels of the last chunk as paired taps (in place, once per upload)
+    {      // Cin 144 / 144 / 112: the 16 real channels of the last chunk as paired taps (in place, once per upload)
         auto pair = [&](ConvL& L) -> int {
             Blob& bl = e->blobs[L.name + ".w"];          // exists: get_conv found it
             if (!bl.paired && launch_pair_ragged(const_cast<half_t*>(L.w), L.Cout_pad, (L.Cin + 31) / 32, L.KD, L.KH, L.KW, 0)) return -1;
             bl.paired = true; L.ragged = true;
             return 0;
         };
-        if (big160()) { TRY(pair(e->w_tail)); TRY(pair(e->w_mask)); }
-        if (enc256()) TRY(pair(e->w_enc[0]));
+        TRY(pair(e->w_tail)); TRY(pair(e->w_mask));
+        TRY(pair(e->w_enc[0]));
     }
     TRY(get_f32(e, "W.mask.b", 32, &e->mask_b));
     TRY(get_conv(e, "W.occp", 16 * 160, 32, 16, 1, 7, 1, 0, 2272.0 * 49, &e->w_occ));
@@ -1671,8 +1614,8 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
         const bool is3d = p.KD > 1;
         set_tile(p, BM, d->tile_w ? d->tile_w : (is3d ? 8 : 16), d->tile_h ? d->tile_h : (is3d ? 8 : BM / 16));
         const int ck = d->ck ? d->ck : ((!is3d && p.Cin % 64 == 0) ? 64 : 32);
-        p.xcd_map = d->xcd_map > 0 ? d->xcd_map - 1 : xcd_map_default();
-        p.persist_total = halo_persist_default();
+        p.xcd_map = d->xcd_map > 0 ? d->xcd_map - 1 : XCD_MAP;
+        p.persist_total = HALO_PERSIST;
         p.ragged = d->ragged;
         p.ep_general = d->ep_general;
         return launch_conv_halo(p, hcfg, ck, c.mode, (hipStream_t)stream);

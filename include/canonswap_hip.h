@@ -23,7 +23,7 @@ extern "C" {
 typedef struct cs_engine cs_engine;
 
 /* ---- life cycle (replaces can_swapper.__init__ / load_cpk, src/can_swap_e2e.py:44-100) */
-int cs_create(int device_id, int max_batch, cs_engine** out);   /* 1 <= max_batch <= 64; workspace ~0.35 GB per frame of batch */
+int cs_create(int device_id, int max_batch, cs_engine** out);   /* 1 <= max_batch <= 84 (32-bit element offsets inside one tensor); workspace ~0.35 GB per frame of batch; 64 is the fastest launch size (profiles/r05_b_batch_sweep.txt) */
 void cs_destroy(cs_engine* e);
 const char* cs_last_error(void);
 #define CS_ABI_VERSION 3       /* bumped whenever a struct of this header, an entry point's meaning or the weight blob format changes */

@@ -203,7 +203,7 @@ def test_animate_frames_v2i(swapper, case, state_dicts):
 def test_max_batch_guard():
     from canonswap_amd.engine import Engine
     with pytest.raises(RuntimeError, match="max_batch"):
-        Engine(0, max_batch=65)
+        Engine(0, max_batch=85)
 
 
 def test_prepare_on_device_bit_exact(swapper):
