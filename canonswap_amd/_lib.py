@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "conv_wide.hip", "vol32.hip", "vol32_fused.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("conv_halo.hip", "conv_wide.hip", "conv_lat.hip", "vol32.hip", "vol32_fused.hip", "kernels.hip", "motion.hip", "imgops.hip", "engine.hip")]
 # test-only cross-check kernel (the first-generation implicit-GEMM conv): its own library, never linked into the product
 TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "csrc", "test_igemm.hip")
 TEST_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "libcanonswap_test.so")
@@ -126,6 +126,7 @@ def isa_check(obj_dir: str | None = None) -> dict:
     if not os.path.exists(objdump):
         raise FileNotFoundError(f"isa_check: {objdump} not found")      # build() reports the check as skipped; a failed check is a RuntimeError
     seen = dict(_isa_check_wide(obj_dir, objdump))
+    seen.update(_isa_check_lat(obj_dir, objdump))
     for g in range(HALO_NGROUPS):
         obj = os.path.join(obj_dir, f"conv_halo_g{g}.o")
         subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True)
@@ -167,6 +168,61 @@ def isa_check(obj_dir: str | None = None) -> dict:
             seen[name] = len(waits)
     if not seen:
         raise RuntimeError("isa_check: no dynamic-shape conv_halo kernel found in the objects (name mangling changed?)")
+    return seen
+
+
+def _isa_check_lat(obj_dir: str, objdump: str) -> dict:
+    """conv_lat.hip stages its halo with LDS-DMA instructions hidden from the compiler (inline asm) next to compiler-counted weight loads,
+    and waits for a chunk's DMA at the chunk's head with a hand-counted `s_waitcnt vmcnt(N)` + `s_barrier`.  vmcnt retires in order, so the
+    wait covers a DMA piece iff at least N vector-memory instructions were issued after it.  Check that for every DMA piece of every such
+    kernel at the first barrier-wait behind it, and that 8 chunks x 6 K-steps of MFMAs sit between 10 barriers (straight-line code)."""
+    import re
+    oname = "conv_lat.o"
+    obj = os.path.join(obj_dir, oname)
+    subprocess.run([objdump, "--offloading", obj], check=True, capture_output=True)
+    co = obj + ".0.hipv4-amdgcn-amd-amdhsa--gfx950"
+    try:
+        txt = subprocess.run([objdump, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    finally:
+        for f in os.listdir(obj_dir):
+            if f.startswith(oname + ".0."):
+                os.remove(os.path.join(obj_dir, f))
+    seen = {}
+    for m in re.finditer(r"^[0-9a-f]+ <(\S*conv_lat_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", txt, re.S | re.M):
+        name, body = m.group(1), [l.split("//")[0].strip() for l in m.group(2).split("\n")]
+        body = [l for l in body if l]
+        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+        if not mf:
+            raise RuntimeError(f"isa_check: {name}: no MFMA")
+        if any(l.startswith(("s_cbranch", "s_branch")) for l in body[mf[0]:mf[-1]]):
+            raise RuntimeError(f"isa_check: {name}: a branch inside the K loop (the walk assumes straight-line code)")
+        nvm, open_dma, nbar, ndma = 0, [], 0, 0
+        for i, l in enumerate(body[:mf[-1] + 1]):
+            op = l.split()[0]
+            if op.startswith(("global_load", "buffer_load", "global_store", "buffer_store", "scratch_load", "scratch_store")):
+                if op.startswith("buffer_load") and l.endswith("lds"):
+                    open_dma.append(nvm); ndma += 1
+                nvm += 1
+            if op == "s_barrier":
+                nbar += 1
+                # the wait that covers this barrier: the nearest vmcnt wait above it
+                w = next((body[j] for j in range(i - 1, max(i - 6, -1), -1) if body[j].startswith("s_waitcnt") and "vmcnt" in body[j]), None)
+                if w is None and not open_dma:
+                    continue          # (the reduction's barriers behind the last chunk: nothing is in flight)
+                if w is None:
+                    raise RuntimeError(f"isa_check: {name}: barrier {nbar} of the K loop has no vmcnt wait in front of it")
+                n = int(re.search(r"vmcnt\((\d+)\)", w).group(1))
+                for idx in open_dma:      # every piece issued so far is this chunk's (the next chunk's go out behind the barrier)
+                    if nvm - idx - 1 < n:
+                        raise RuntimeError(f"isa_check: {name}: `{w}` before barrier {nbar} does not cover a DMA piece issued {nvm - idx - 1} vector-memory instructions earlier")
+                open_dma = []
+        if open_dma:
+            raise RuntimeError(f"isa_check: {name}: {len(open_dma)} DMA pieces are never waited for at a chunk head")
+        if len(mf) not in (8 * 6 * 8, 8 * 6 * 16) or ndma != 24:
+            raise RuntimeError(f"isa_check: {name}: {len(mf)} MFMAs / {ndma} DMA instructions, expected 384 or 768 / 24")
+        seen[name] = len(mf)
+    if not seen:
+        raise RuntimeError("isa_check: no conv_lat kernel found in conv_lat.o (name mangling changed?)")
     return seen
 
 

@@ -19,7 +19,8 @@ enum { CFG_H_128x128 = 10, CFG_H_128x64 = 11, CFG_H_256x32 = 12, CFG_H_128x32 = 
        CFG_H_128x160 = 18 /* 2x2 waves of 64 positions x 80 channels: the kw-split mask conv */,
        CFG_H_256x160 = 19 /* 2x2 waves of 128 positions x 80 channels, one workgroup per CU: half the weight bytes per MFMA of 128x160 */,
        CFG_H_256x64 = 20 /* 2x2 waves of 128 positions x 32 channels: 3x3x3 on 8x8x4 tiles (the 64-channel hourglass block) and 3x3 on 16x16 tiles (the 64-channel convs of G's last up block) */,
-       CFG_VOL32 = 30 /* vol32.hip (cs_op_conv: force that kernel) */, CFG_WIDE = 31 /* conv_wide.hip (cs_op_conv: force that kernel) */ };
+       CFG_VOL32 = 30 /* vol32.hip (cs_op_conv: force that kernel) */, CFG_WIDE = 31 /* conv_wide.hip (cs_op_conv: force that kernel) */,
+       CFG_LAT = 32 /* conv_lat.hip (cs_op_conv: force that kernel) */ };
 
 // A channels-last tensor view: element strides, channel stride is 1.
 struct TDesc {
@@ -127,6 +128,10 @@ struct ConvParams {
     int persist_total;
     unsigned in_sample_bytes;   // conv_halo's 256 x 160 tiles (set by the launcher): bytes one sample of the input spans, the range of their buffer-addressed halo DMA
     int xf_kind;
+    // vol32 statistics launches: rows of a partial-statistics block (0: the default 8).  Latency mode passes 2: a one-frame launch then cuts its
+    // strips into 2-row segments (256 items instead of 64 on a 64 x 64 volume: every CU gets one); another grouping of the partial sums, i.e.
+    // other last bits of (mean, rstd) than the batched path - like split-K, only behind cs_set_latency_mode
+    int v32_srows;
     TDesc xf_y, xf_res, xf_out;
     const float* xf_stats; const float* xf_gamma; const float* xf_beta;
     float xf_slope;
@@ -183,6 +188,10 @@ int launch_vol32(const ConvParams& p, hipStream_t st);
 // conv_wide.hip: persistent 3x3 kernel for the wide 2-D layers (256 x 256 workgroup tiles, 8 x 8 fragments per wave, one workgroup per CU)
 bool conv_wide_supported(const ConvParams& p, int mode);
 int launch_conv_wide(const ConvParams& p, int mode, hipStream_t st);
+// conv_lat.hip: single-frame kernel for the 512-channel 3x3 layers at 64 x 64 (16 x 8 tiles, the K loop split over the three kernel rows across 12 waves);
+// another summation order than conv_halo / conv_wide: latency mode only
+bool conv_lat_supported(const ConvParams& p, int mode);
+int launch_conv_lat(const ConvParams& p, int mode, hipStream_t st);
 const half_t* cs_zero_page();   // per-process device buffer of zeros (lazily allocated on the current device)
 
 int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);

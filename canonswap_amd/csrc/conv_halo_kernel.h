@@ -420,10 +420,15 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         constexpr bool RAGK = (CK == 32) && (WPX == 8) && (ST == 7 || ST == 8 || ST == 9) && MODE == MODE_STD;
         // weight ring depth; the ring is re-primed at every chunk.  Three steps cover an L2 round trip where a step is 16-40 MFMAs; the
         // 16- and 32-channel tiles run 2-4 MFMAs per step and were bound by that latency (T's mask conv: 80 us for 134 MB): 8 steps
+        // LATK: the 128 x 64 tiles of the 512-channel 3x3 convs (64-channel chunks, 4 x 2 fragments per wave) only run below three frames
+        // per launch: one workgroup per CU, one wave per SIMD, and the weights come from HBM (every conv's set is read once per frame).  A ring
+        // of 6 steps carried over the chunk boundary: R's 2-D convs 0.251 -> 0.215 ms, G's 512 -> 512 convs -9 % on the one-frame step
+        // (profiles/r05_e_ab_lat_ring.txt).  The 128 x 128 tiles (T, SPADE; 168-register budget) lose with the deeper ring: not taken there.
+        constexpr bool LATK = CK == 64 && WCH == 2 && WPX == 4 && ST == 1 && !SK;
 #ifdef CS_PFS3
         constexpr int PFS = NS < 3 ? NS : 3;
 #else
-        constexpr int PFS = NS < 3 ? NS : (WCH * WPX <= 4 ? (NS < 8 ? NS : 8) : 3);
+        constexpr int PFS = NS < 3 ? NS : (WCH * WPX <= 4 ? (NS < 8 ? NS : 8) : (LATK ? (NS < 6 ? NS : 6) : 3));
 #endif
         // The ring is carried over the chunk boundary in the kernels that run one wave per SIMD (256-position tiles), where a chunk is a
         // whole number of ring turns (3x3x3 x 32 channels: 27 steps): the last PFS steps of a chunk fetch the first PFS steps of the next
@@ -439,7 +444,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #ifdef CS_WCARRY_MULT
         constexpr bool WCARRY = (NS % PFS == 0) && NS >= 2 * PFS && WPX == 8 && WVP == 2;
 #else
-        constexpr bool WCARRY = NS >= 2 * PFS && WPX == 8 && WVP == 2;
+        constexpr bool WCARRY = NS >= 2 * PFS && ((WPX == 8 && WVP == 2) || LATK);
 #endif
 #endif
         constexpr int SHW = (1 << SS::LW) + SS::KW - 1, SHH = (1 << SS::LH) + SS::KH - 1;

@@ -323,6 +323,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     // on the halo kernel there, one frame 6.75 -> 6.5 ms; the statistics / transform-staging convs of R always run vol32: their partial
     // statistics are laid out per kernel, and a frame's bits must not depend on the batch it is part of)
     if (vol32_enabled() && vol32_supported(c.p) && (c.p.N >= VOL32_MINB || c.p.stat_out || c.p.xf_kind)) {
+        if (e->latency_mode && c.p.stat_out) c.p.v32_srows = 2;      // 2-row segments: 256 items on one frame's 64 x 64 volume (common.h)
         c.stat_nblk = vol32_stat_nblk(c.p);
         TRY(e->run(0, st, [&] { return launch_vol32(c.p, st); }, c.name, fl));
         return amax_after(e, c, st);
@@ -340,6 +341,16 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             TRY(e->run(0, st, [&] { return launch_conv_wide(c.p, c.mode, st); }, c.name, fl));
             return amax_after(e, c, st);
         }
+    }
+    // single-frame mode: the 512-channel 3x3 layers at 64 x 64 (T blend, G_middle / up_0, R's 2-D pair, W.third) on conv_lat.hip - the 16 x 8 tile
+    // with its K loop split over the three kernel rows across 12 waves - while the launch is one workgroup per CU or less.  Another summation
+    // order than the batched path: only behind cs_set_latency_mode (CANONSWAP_LAT=0: A/B knob, conv_halo's four-wave tiles)
+    static const int lat_on = [] { const char* s = getenv("CANONSWAP_LAT"); return s ? atoi(s) : 1; }();
+    if (lat_on && e->latency_mode && c.hcfg < 0 && conv_lat_supported(c.p, c.mode) &&
+        (long)c.p.N * (c.p.H / 8) * (c.p.W / 16) * (c.p.Cout_pad / (c.mode == MODE_TBLEND ? 128 : 64)) <= 256) {
+        c.stat_nblk = (c.p.W / 16) * (c.p.H / 8) * 2;      // partial-statistics blocks per sample: 64 positions each, in the 16 x 8 tiles' order
+        TRY(e->run(0, st, [&] { return launch_conv_lat(c.p, c.mode, st); }, c.name, fl));
+        return amax_after(e, c, st);
     }
     if (c.p.inD == c.p.D) {
         const int hcfg = c.hcfg >= 0 ? c.hcfg : pick_halo_cfg(c.p, c.mode);
@@ -447,7 +458,7 @@ bool vol32_fused_on() { static const bool on = [] { const char* s = getenv("CANO
 int run_resblocks3d(cs_engine* e, cs_engine::RB3* rb, int B, int* cur, const Affine* final_post, int final_act, hipStream_t st)
 {
     // util.py:94-102; a = relu(bn1(x)) is already in va[0]; x (fp32 residual stream) in vs[*cur]
-    if (vol32_fused_on() && B >= VOL32_MINB) {
+    if (vol32_fused_on()) {      // at every batch size (one frame: 2-row segments, launch_vol32_fused); the same bits as the two-launch path below
         // block i reads a from va[i & 1] and leaves the next block's a in va[(i + 1) & 1] (a neighbouring workgroup still reads the halo
         // columns of the input while this one stores): six blocks end in va[0] again
         for (int i = 0; i < 6; ++i) {
@@ -1608,6 +1619,7 @@ extern "C" int cs_op_conv(const cs_conv_desc* d, void* stream)
     if (d->mode == 5) { c.mode = MODE_STD; p.spmul = 1; }     // out0 = act0(IN(res) (1 + conv + bias)): ConvParams::spmul
     if (d->cfg == CFG_VOL32) return launch_vol32(p, (hipStream_t)stream);
     if (d->cfg == CFG_WIDE) return launch_conv_wide(p, c.mode, (hipStream_t)stream);
+    if (d->cfg == CFG_LAT) return launch_conv_lat(p, c.mode, (hipStream_t)stream);
     if (d->cfg >= 10 || d->cfg == -2) {      // conv_halo
         const int hcfg = d->cfg >= 10 ? d->cfg : pick_halo_cfg(p, c.mode);
         const int BM = (hcfg == CFG_H_256x32 || hcfg == CFG_H_256x16 || hcfg == CFG_H_256x160 || hcfg == CFG_H_256x64) ? 256 : 128;

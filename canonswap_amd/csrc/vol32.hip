@@ -72,6 +72,7 @@ struct Vol32Params {
     half_t* out1; int o1_sN, o1_sH, o1_sW;
     const float* s2; const float* t2;
     float* stat_out; int stat_nblk;          // [N][stat_nblk][32][2] partial (sum, sum of squares) of the stored out0 values
+    int srows;                               // rows of a partial-statistics block (V_SROWS; 2 in latency mode)
     // transform staging (XF kernels; ConvParams::xf_*)
     const float* xf_y; int xy_sN, xy_sH, xy_sW;
     const float* xf_res; int xr_sN, xr_sH, xr_sW;
@@ -507,8 +508,8 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 }
             }
             if constexpr (EPI == V_EPI_STAT) {
-                if (((h + 1) % V_SROWS) == 0 || h + 1 == h1) {      // the block (column pair, rows [8k, 8k + 8)) is complete: fixed-order butterfly
-                    const int blk = (h / V_SROWS) * (p.W / 2) + (w0 / 2 + wave);
+                if (((h + 1) % p.srows) == 0 || h + 1 == h1) {      // the block (column pair, rows [8k, 8k + 8)) is complete: fixed-order butterfly
+                    const int blk = (h / p.srows) * (p.W / 2) + (w0 / 2 + wave);
                     float pa[8], pb[8];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
@@ -598,7 +599,8 @@ bool vol32_supported(const ConvParams& p)
 }
 
 // partial-statistics blocks per sample of a vol32 launch with ConvParams::stat_out
-int vol32_stat_nblk(const ConvParams& p) { return ((p.H + V_SROWS - 1) / V_SROWS) * (p.W / 2); }
+static int vol32_srows(const ConvParams& p) { return p.v32_srows > 0 ? p.v32_srows : V_SROWS; }
+int vol32_stat_nblk(const ConvParams& p) { const int sr = vol32_srows(p); return ((p.H + sr - 1) / sr) * (p.W / 2); }
 
 int launch_vol32(const ConvParams& p, hipStream_t st)
 {
@@ -621,7 +623,7 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     k.out0 = p.out0.p; k.o0_sN = (int)p.out0.sN; k.o0_sH = (int)p.out0.sH; k.o0_sW = (int)p.out0.sW;
     k.out1 = (half_t*)p.out1.p; k.o1_sN = (int)p.out1.sN; k.o1_sH = (int)p.out1.sH; k.o1_sW = (int)p.out1.sW;
     k.s2 = p.s2; k.t2 = p.t2;
-    k.stat_out = p.stat_out; k.stat_nblk = vol32_stat_nblk(p);
+    k.stat_out = p.stat_out; k.stat_nblk = vol32_stat_nblk(p); k.srows = vol32_srows(p);
     k.xf_y = (const float*)p.xf_y.p; k.xy_sN = (int)p.xf_y.sN; k.xy_sH = (int)p.xf_y.sH; k.xy_sW = (int)p.xf_y.sW;
     k.xf_res = (const float*)p.xf_res.p; k.xr_sN = (int)p.xf_res.sN; k.xr_sH = (int)p.xf_res.sH; k.xr_sW = (int)p.xf_res.sW;
     k.xf_out = (float*)p.xf_out.p; k.xo_sN = (int)p.xf_out.sN; k.xo_sH = (int)p.xf_out.sH; k.xo_sW = (int)p.xf_out.sW;
@@ -642,7 +644,7 @@ int launch_vol32(const ConvParams& p, hipStream_t st)
     // rows per item: whole strips when they fill the chip, else the strips are cut along H (a segment re-stages two halo rows, it never
     // recomputes anything) down to 8 rows (= one statistics block).  Per output element nothing depends on the decomposition.
     int nseg = 1;
-    while ((long)p.N * k.nstrips * nseg < g_ncu && (p.H % (nseg * 2 * V_SROWS)) == 0) nseg *= 2;
+    while ((long)p.N * k.nstrips * nseg < g_ncu && (p.H % (nseg * 2 * k.srows)) == 0) nseg *= 2;
     k.seg_rows = (p.H + nseg - 1) / nseg;
     k.nseg = (p.H + k.seg_rows - 1) / k.seg_rows;
     k.items = p.N * k.nstrips * k.nseg;

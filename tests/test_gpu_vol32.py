@@ -261,11 +261,12 @@ def _resblock_fused(a16, x32, w1p, w2p, b1, b2, s2, t2, act1):
     return out0, out1
 
 
-@pytest.mark.parametrize("N,H,W", [(3, 64, 64), (32, 64, 64), (1, 64, 64), (2, 24, 16), (5, 2, 8), (1, 1, 8), (2, 9, 24)])
+@pytest.mark.parametrize("N,H,W", [(3, 64, 64), (32, 64, 64), (1, 64, 64), (2, 64, 64), (1, 32, 24), (2, 24, 16), (5, 2, 8), (1, 1, 8), (2, 9, 24)])
 @pytest.mark.parametrize("post", [True, False])
 def test_fused_resblock3d_equals_two_launches(N, H, W, post):
     """vol32_fused.hip: a whole ResBlock3d (util.py:80-102) per launch against conv1 -> conv2 as two vol32 launches (which equal the halo
-    kernel bit for bit, tests above): torch.equal on both outputs, and against torch fp32 at the usual tolerance."""
+    kernel bit for bit, tests above): torch.equal on both outputs, and against torch fp32 at the usual tolerance.  One or two frames of a
+    64 x 64 volume run 2- / 4-row segments (launch_vol32_fused): the decomposition does not show in the bits."""
     import hip_ops as ops
     r = _rng(3000 + 7 * N + 3 * H + W + int(post))
     Cc, D = 32, 16
@@ -293,25 +294,26 @@ def test_fused_resblock3d_equals_two_launches(N, H, W, post):
     assert ops.rel_err(_back(got0), y) < 2e-3
 
 
-def test_engine_feature_extractor_fused_vs_two_launches(state_dicts):
-    """F (appearance_feature_extractor.py:38-48: six ResBlock3d) and T's six through the engine with the fused kernel (default) and with two
-    launches per block (CANONSWAP_VOL32_FUSED=0, subprocess): identical bits."""
+@pytest.mark.parametrize("B", [3, 1])
+def test_engine_feature_extractor_fused_vs_two_launches(state_dicts, B):
+    """F (appearance_feature_extractor.py:38-48: six ResBlock3d) and T's six through the engine with the fused kernel (default, at every
+    batch size) and with two launches per block (CANONSWAP_VOL32_FUSED=0, subprocess): identical bits."""
     import os
     import subprocess
     import sys
     from canonswap_amd import synth
     from canonswap_amd.can_swap_e2e import can_swapper
-    inp = synth.make_frame_inputs(3, seed=33, size=256)
+    inp = synth.make_frame_inputs(B, seed=33, size=256)
     img = torch.from_numpy(inp["img"])
     idv = torch.from_numpy(synth.make_identity(7))
-    sw = can_swapper(None, state_dicts=state_dicts, max_batch=3)
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=B)
     f = sw.extract_feature_3d(img.cuda())
     got = torch.cat([f.cpu(), sw.swap_module(f, idv.cuda()).cpu()])
     code = ("import torch, sys; sys.path.insert(0, %r); from canonswap_amd import synth; from canonswap_amd.can_swap_e2e import can_swapper;"
-            "sd = synth.to_torch(synth.make_state_dicts(0)); sw = can_swapper(None, state_dicts=sd, max_batch=3);"
-            "img = torch.from_numpy(synth.make_frame_inputs(3, seed=33, size=256)['img']); idv = torch.from_numpy(synth.make_identity(7));"
+            "sd = synth.to_torch(synth.make_state_dicts(0)); sw = can_swapper(None, state_dicts=sd, max_batch=%d);"
+            "img = torch.from_numpy(synth.make_frame_inputs(%d, seed=33, size=256)['img']); idv = torch.from_numpy(synth.make_identity(7));"
             "f = sw.extract_feature_3d(img.cuda()); torch.save(torch.cat([f.cpu(), sw.swap_module(f, idv.cuda()).cpu()]), sys.argv[1])"
-            ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), B, B)
     env = dict(os.environ, CANONSWAP_VOL32_FUSED="0")
     r = subprocess.run([sys.executable, "-c", code, "/tmp/fused_off.pt"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

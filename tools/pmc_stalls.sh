@@ -11,7 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_VMEM_TA_ADDR_FIFO_FULL"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/p$i.json 2> $OUT/p$i.err
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o pmc --output-format csv -- python /root/repo/bench.py --steps ${PMC_STEPS:-1} --warmup 1 --no-cpu-baseline --no-fixed-job $BENCH_ARGS > $OUT/p$i.json 2> $OUT/p$i.err
   rm -f $OUT/p$i/pmc_kernel_trace.csv
 done
 du -sh $OUT
