@@ -1135,7 +1135,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         return -1;
     }
     if (p.inD != p.D) { cs_set_error("conv_halo: depth-collapsing convs are not supported"); return -1; }
-    if (p.pool_hw) {
+    if (p.pool_hw && !p.sk_out) {      // (a split-K launch leaves raw partial sums: its finishing launch pools)
         using SSL = StaticShape<ST>;
         constexpr bool poolk = ST != 0 && !SK && MODE == MODE_STD && WCH == 2 && SSL::KD == 3 && SSL::KH == 3 && SSL::KW == 3 && (SSL::LW == 3 || SSL::LW == 2) && SSL::LH >= 1;
         constexpr bool poolk2 = halo_pool2d<CK, WPX, WCH, WVP, MODE, SK, ST>();

@@ -380,7 +380,8 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const int nck = (c.p.Cin + ck - 1) / ck;
             const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
             const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
-                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0 && !c.p.pool_hw && !c.p.spmul;
+                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0 && !c.p.spmul &&
+                               (!c.p.pool_hw || (!c.p.out0_f32 && !(c.p.H & 1) && !(c.p.W & 1)));      // (pooled: the finishing launch averages)
             constexpr int sk_maxwg = 64, sk_fill = 512;      // r02 sweep
             if (sk_on && plain && wgs <= sk_maxwg && nck >= 4 && e->sk_buf) {
                 int splits = (int)(sk_fill / wgs);
@@ -559,15 +560,10 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         if (i == 0) c.hcfg = CFG_H_256x64;      // 64 channels at 64x64: 256-position tiles (0.65 -> 0.47 ms per 16 frames)
         TDesc o = dhwc(e->dm_l[i + 1] + skip_off[i + 1], FD, S / 2, S / 2, lw[i + 1]);
         // AvgPool3d((1,2,2)) of the block (util.py:189) inside the conv's epilogue: the average of the four fp32 values, rounded once, goes
-        // straight into the next level's concat buffer - no full-resolution tensor, no pooling launch.  Latency mode keeps
-        // the two launches (its split-K convs leave partial sums; the average is then taken over fp16-rounded values).
-        if (!e->latency_mode) {
-            c.p.pool_hw = 1; c.p.out0 = o;
-            TRY(go(e, c, st));
-            continue;
-        }
+        // straight into the next level's concat buffer - no full-resolution tensor, no pooling launch.  In latency mode
+        // too: the finishing launch of a split-K conv averages the same way (splitk_finish_pool_kernel).
+        c.p.pool_hw = 1; c.p.out0 = o;
         TRY(go(e, c, st));
-        TRY(e->run(1, st, [&] { return launch_avgpool(e->dm_pre, B, FD, S, S, cout[i], o, st); }, "avgpool"));
     }
     for (int i = 0; i < 5; ++i) {       // Decoder: UpBlock3d (util.py:142-147), nearest x(1,2,2) folded into addressing
         const int lv = 5 - i, S = 64 >> (lv - 1), Si = S / 2;

@@ -894,10 +894,13 @@ __device__ __forceinline__ float tm_dot8(const uint4& v, const uint4& q, float a
     a = __builtin_amdgcn_fdot2(__builtin_bit_cast(tm_h2, v.z), __builtin_bit_cast(tm_h2, q.z), a, false);
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(tm_h2, v.w), __builtin_bit_cast(tm_h2, q.w), a, false);
 }
+// SEG: output columns a wave marches over (16; 4 for launches of fewer than 1024 waves - one or two frames -, where 64 x 4 waves of 18 dependent
+// column steps leave three quarters of the CUs idle: 10 -> 5 us per launch at one frame).  Per output the same sums in the same order: same bits.
+template <int SEG>
 __global__ void __launch_bounds__(256, 4) t_mask_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp, const float* __restrict__ bias,
                                                         float* __restrict__ tmask, int N, int H, int W)
 {
-    constexpr int SEG = 16, RS = 65;                        // LDS row stride 65 floats: the reduction's reads are conflict-free
+    constexpr int RS = 65;                                  // LDS row stride 65 floats: the reduction's reads are conflict-free
     __shared__ float part[4][SEG * RS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nseg = W / SEG;
@@ -952,10 +955,10 @@ __global__ void __launch_bounds__(256, 4) t_mask_kernel(const half_t* __restrict
     const int o = lane >> 2, q = lane & 3;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sum += part[wave][o * RS + q * 16 + i];
+    for (int i = 0; i < 16; ++i) sum += part[wave][(o < SEG ? o : 0) * RS + q * 16 + i];
     sum += __shfl_xor(sum, 1, 64);
     sum += __shfl_xor(sum, 2, 64);
-    if (q == 0) {
+    if (q == 0 && o < SEG) {
         const float y = sum + bias[0];
         tmask[(((long)n * H + h) * W + w0 + o) * 4] = 1.f / (1.f + __expf(-y));
     }
@@ -1062,7 +1065,9 @@ int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, flo
     if (W % 16 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)wpacked & 15)) { cs_set_error("t_mask: width a multiple of 16, 16-byte aligned tensors"); return -1; }
     const long items = (long)N * H * (W / 16);
     if (items % 4 != 0) { cs_set_error("t_mask: N * H * W / 16 must be a multiple of 4"); return -1; }
-    hipLaunchKernelGGL(t_mask_kernel, dim3((unsigned)cdiv(items, 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
+    // (the segment length may depend on N: it does not change a bit of the result, tests/test_gpu_ops.py)
+    if (items < 1024) hipLaunchKernelGGL(t_mask_kernel<4>, dim3((unsigned)items), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
+    else hipLaunchKernelGGL(t_mask_kernel<16>, dim3((unsigned)cdiv(items, 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
     LAUNCH_CHECK("t_mask");
     return 0;
 }
@@ -1205,11 +1210,48 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const ConvParams p, 
     }
 }
 
+// ... with ConvParams::pool_hw: out0 = AvgPool(1,2,2) of the activated values, on the pooled grid (DownBlock3d, util.py:185-190): a thread finishes
+// the four positions of a window and averages their fp32 values in the epilogue's order, (a + b) + (c + d) with b the w + 1 and c the h + 1
+// neighbour (conv_epilogue.h, EP_POOL), rounded once - no full-resolution tensor, no pooling launch in latency mode either
+__global__ void __launch_bounds__(256) splitk_finish_pool_kernel(const ConvParams p, long mtot)
+{
+    const int cq = p.Cout / 4;
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (mtot >> 2) * cq) return;
+    long r = i / cq;
+    const int c = (int)(i % cq) * 4;
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h2 = (int)(r % H2); r /= H2;
+    const int d = (int)(r % p.D); r /= p.D;
+    float a[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long pos = ((r * p.D + d) * p.H + 2 * h2 + (j >> 1)) * p.W + 2 * w2 + (j & 1);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.sk_splits; ++k) {
+            const float4 q = *(const float4*)(p.sk_out + ((long)k * mtot + pos) * p.Cout_pad + c);
+            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[j][k] = act_f(v[k] + (p.bias ? p.bias[c + k] : 0.f), p.act0, p.slope0);
+    }
+    const long o = r * p.out0.sN + (long)d * p.out0.sD + (long)h2 * p.out0.sH + (long)w2 * p.out0.sW + c;
+    h4_t x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = (half_t)(((a[0][k] + a[1][k]) + (a[2][k] + a[3][k])) * 0.25f);
+    *(h4_t*)((half_t*)p.out0.p + o) = x;
+}
+
 int launch_splitk_finish(const ConvParams& p, hipStream_t st)
 {
     if (p.res.p || p.pixscale || p.out1.p || p.stat_out || p.s2) { cs_set_error("split-K finish: only bias + activation + one output"); return -1; }
     const long mtot = (long)p.N * p.D * p.H * p.W;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(cdiv(mtot * (p.Cout / 4), 256)), dim3(256), 0, st, p, mtot);
+    if (p.pool_hw) {
+        if (p.out0_f32 || (p.H & 1) || (p.W & 1)) { cs_set_error("split-K finish: the pooled form stores fp16 on an even grid"); return -1; }
+        hipLaunchKernelGGL(splitk_finish_pool_kernel, dim3(cdiv((mtot >> 2) * (p.Cout / 4), 256)), dim3(256), 0, st, p, mtot);
+    } else
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(cdiv(mtot * (p.Cout / 4), 256)), dim3(256), 0, st, p, mtot);
     LAUNCH_CHECK("splitk_finish");
     return 0;
 }

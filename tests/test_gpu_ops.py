@@ -403,6 +403,23 @@ def test_t_mask_valu_kernel(N, H, W):
     assert float((out[..., 0] - halo[:, 0, ..., 0]).abs().max()) < 2e-5
 
 
+def test_t_mask_segment_length_does_not_change_bits():
+    """Launches of fewer than 1024 waves (one or two 64 x 64 frames) run t_mask_kernel with 4-column segments, larger ones with 16-column
+    segments (kernels.hip, launch_t_mask): a frame alone and the same frame inside a batch of eight give the same bits."""
+    import hip_ops as ops
+    r = _rng(771)
+    x = F.relu(_randn(r, 8, 512, 64, 64))
+    w = _randn(r, 1, 512, 3, 3, scale=2.0 / np.sqrt(512 * 9))
+    b = _randn(r, 4, scale=0.1)
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    wp = ops.packed_weight(w.unsqueeze(2), 16, DEV)
+    big = ops.t_mask(xd, wp, b.to(DEV))
+    for n in (0, 5):
+        one = ops.t_mask(xd[n:n + 1].contiguous(), wp, b.to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], big[n])
+
+
 @pytest.mark.parametrize("stat", [False, True])
 def test_conv_256x64_tile_2d(stat):
     """3x3, 128 -> 64 (G's last up block / F's first down block) on the 2-D 256-position x 64-channel tile (16x16) against the 128x64
