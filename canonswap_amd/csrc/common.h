@@ -127,6 +127,12 @@ struct ConvParams {
     // block) entries, or by 0 where the kernel has no such mode.
     int persist_total;
     unsigned in_sample_bytes;   // conv_halo's 256 x 160 tiles (set by the launcher): bytes one sample of the input spans, the range of their buffer-addressed halo DMA
+    // conv_halo: up to four convolutions that differ in their weights, their leading padding and an offset into out0 only - the output phases of an
+    // up-sampling conv on the source grid (pack.upsampled_conv3d_phases) - as ONE launch, blockIdx.z = phase.  0: off.  Not with split-K.
+    int nphase;
+    long ph_wofs[4];          // element offset of phase z's packed weights from wgt
+    unsigned ph_ooff[4];      // element offset of phase z's outputs inside out0
+    int ph_PH[4], ph_PW[4];   // PH / PW of phase z
     int xf_kind;
     // vol32 statistics launches: rows of a partial-statistics block (0: the default 8).  Latency mode passes 2: a one-frame launch then cuts its
     // strips into 2-row segments (256 items instead of 64 on a 64 x 64 volume: every CU gets one); another grouping of the partial sums, i.e.

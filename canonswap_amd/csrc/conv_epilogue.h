@@ -266,6 +266,9 @@ _Pragma("unroll") \
 #ifndef EP_PIPE_V
 #define EP_PIPE_V 0
 #endif
+#ifndef EP_O0_EXTRA_V
+#define EP_O0_EXTRA_V 0u      /* element offset added to every out0 address (conv_halo: the output phase of a grouped launch, ConvParams::nphase) */
+#endif
 /* AvgPool(1,2,2) of out0 inside the epilogue (ConvParams::pool_hw; DownBlock3d, util.py:185-190; DownBlock2d, util.py:150-165): the four
    positions of a window are four lanes of one 16-position block; a kernel that supports it names the two DPP row shifts (in lanes) that reach
    the w + 1 and h + 1 neighbours under its lane -> position map.  WSH > 0 with HSH == 0: the blocks are rows of 16 columns (2-D 16 x 8
@@ -386,7 +389,7 @@ _Pragma("unroll") \
     const bool ep_tn1 = (BM >> lgS) == 1; \
     const unsigned ep_lane_res = (unsigned)(ep_nb * (int)p.res.sN + (ep_tn1 ? 0 : ep_ln * (int)p.res.sN) + __mul24(ep_d0 + ep_ld, (int)p.res.sD) + \
                                             __mul24((ep_h0 + ep_lh) >> ep_rs, (int)p.res.sH) + __mul24((ep_w0 + ep_lw) >> ep_rs, (int)p.res.sW)); \
-    const unsigned ep_lane_o0 = (unsigned)(ep_nb * (int)p.out0.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out0.sN) + __mul24(ep_d0 + ep_ld, (int)p.out0.sD) + \
+    const unsigned ep_lane_o0 = (EP_O0_EXTRA_V) + (unsigned)(ep_nb * (int)p.out0.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out0.sN) + __mul24(ep_d0 + ep_ld, (int)p.out0.sD) + \
                                            __mul24((ep_h0 + ep_lh) >> EP_PS, (int)p.out0.sH) + __mul24((ep_w0 + ep_lw) >> EP_PS, (int)p.out0.sW)); \
     /* pooled: the lanes whose position is the (even h, even w) corner of a window hold the window's sum and store it */ \
     const bool ep_pool_lane = !EP_POOL || (lane & ((EP_POOL_WSH_V) | (EP_POOL_HSH_V))) == 0; \

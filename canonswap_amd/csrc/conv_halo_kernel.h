@@ -26,6 +26,7 @@
 #define EP_POOL_WSH_V EP_POOL_WSH_K      /* lane shifts of the pooling epilogue: per instantiation, from the lane -> position map (below) */
 #define EP_POOL_HSH_V EP_POOL_HSH_K
 #define EP_SPMUL_V EP_SPMUL_K            /* kernels that carry a branch-free copy of the spmul epilogue (below) */
+#define EP_O0_EXTRA_V ep_o0_extra        /* the output phase of a grouped launch (ConvParams::nphase; 0 otherwise) */
 #include "conv_epilogue.h"
 
 // Weight fragments are streamed with loads the compiler does not track (inline asm) and are waited for with an
@@ -168,6 +169,9 @@ template <int ST, int PAD> constexpr int halo_pool_shift(int bit)
     return 0;
 }
 
+// kernels that can run a grouped launch (ConvParams::nphase)
+template <int WCH, int ST> constexpr bool halo_phase_group() { return !(ST == 0 && WCH >= 4); }
+
 // kernels that carry the 2-D pooling epilogue (conv_epilogue.h, EP_POOL_HB)
 template <int CK, int WPX, int WCH, int WVP, int MODE, bool SK, int ST> constexpr bool halo_pool2d()
 {
@@ -229,6 +233,13 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // grouped launch (ConvParams::nphase): blockIdx.z picks the phase's weights, leading padding and output offset
+    // (not in the dynamic-shape 128 x 256 kernels: with anything added hipcc re-allocates their hand-counted weight ring - _lib.isa_check - and no
+    // grouped layer runs on them)
+    constexpr bool PHK = halo_phase_group<WCH, ST>();
+    const int phz = (PHK && p.nphase) ? (int)blockIdx.z : 0;
+    const int PHv = (PHK && p.nphase) ? p.ph_PH[phz] : p.PH, PWv = (PHK && p.nphase) ? p.ph_PW[phz] : p.PW;
+    const unsigned ep_o0_extra = (PHK && p.nphase) ? p.ph_ooff[phz] : 0u;
     const int wpx = SK ? 0 : wave % WVP, wch = SK ? 0 : wave / WVP;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int l15p = halo_lane_pos<ST, PAD>(l15);      // the position of its 16-position blocks this lane works on
@@ -311,7 +322,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         const int hh = r % HH; r /= HH;
         const int hd = r % HD;
         const int hn = TN == 1 ? 0 : r / HD;
-        const int n = nb + hn, id = d0 + hd - p.PD, ih = h0 + hh - p.PH, iw = w0 + hw - p.PW;
+        const int n = nb + hn, id = d0 + hd - p.PD, ih = h0 + hh - PHv, iw = w0 + hw - PWv;
         inb = q < nitems && (q % SLP) < SL && (TN == 1 ? r < HD : true) && n < p.N && (unsigned)id < (unsigned)p.D &&
               (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         return in_nb + (TN == 1 ? 0 : hn * isN) + __mul24(id, isD) + __mul24(ih >> p.up_shift, isH) + __mul24(iw >> p.up_shift, isW) +
@@ -385,6 +396,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // weights: fragment ci of K-step kidx = 1 KiB at wgt + (kidx*Cout_pad + n0 + wch*WCH*16 + ci*16)*32; lane = (row l15, k l4*8)
     const half_t* wbase = p.wgt;
     if (p.wslot) wbase += p.wofs[p.wslot[nb < p.N ? nb : p.N - 1]];         // per-sample weight set (uniform over the tile)
+    if (PHK && p.nphase) wbase += p.ph_wofs[phz];
     // EP_PAIR (conv_epilogue.h): the rows of a fragment pair are permuted so that a lane ends up with 8 consecutive output channels
     const half_t* wlane = wbase + ((long)(n0 + wch * WCH * 16) * 32 + ep_lane_row(EP_PAIR, l15) * 32 + l4 * 8);
     const long wstep = (long)p.Cout_pad * 32;
@@ -477,7 +489,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
                     const int hv = q / SLP, sl = q % SLP;
                     const int hw = hv % HW; int r = hv / HW;
                     const int hh = r % HH; r /= HH;
-                    const int id = d0_ + r - p.PD, ih = h0_ + hh - p.PH, iw = w0_ + hw - p.PW;
+                    const int id = d0_ + r - p.PD, ih = h0_ + hh - PHv, iw = w0_ + hw - PWv;
                     const bool inb = q < nitems && sl < SL && r < HD && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                     poffb[j] = inb ? (unsigned)(__mul24(id, isD) + __mul24(ih >> p.up_shift, isH) + __mul24(iw >> p.up_shift, isW) + sl * 8) * 2u : OOB;
                 }
@@ -1218,11 +1230,15 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         cs_set_error("conv_halo: the hi/lo split-precision mode needs a static-shape 32-channel kernel with three single-buffered chunks");
         return -1;
     }
+    if (p.nphase) {
+        if (SK || !halo_phase_group<WCH, ST>() || p.nphase < 1 || p.nphase > 4 || p.sk_out || p.kw_out || p.xs_w || p.persist_total < 0) { cs_set_error("conv_halo: bad grouped launch (%d phases)", p.nphase); return -1; }
+        grid.z = (unsigned)p.nphase;
+    }
     if (p.sk_out) {
         if (SK || p.sk_splits < 1 || p.sk_splits > nck || p.xcd_map == 2) { cs_set_error("conv_halo: bad split-K launch (%d splits, %d chunks)", p.sk_splits, nck); return -1; }
         grid.z = (unsigned)p.sk_splits;
     }
-    if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1);
+    if (p.xcd_map == 2) grid = dim3(grid.x * grid.y, 1, grid.z);
     hipError_t e;
     {   // exact division of the workgroup index by the tile counts as one multiply-high each (u / d == umulhi(u, 2^32 / d + 1) while
         // u * d < 2^32; 0 encodes d == 1): four runtime integer divisions cost every workgroup about a hundred issue slots
@@ -1238,7 +1254,7 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
 #ifdef CS_TIMELINE
     kp.tl = g_cs_tl; kp.tl_cap = g_cs_tl_cap;
 #endif
-    if (asmr && db && p.persist_total != 0 && !p.sk_out) {          // persistent: one workgroup per CU (LDS: one resident), XCD x walks entries [x * total / 8 ...)
+    if (asmr && db && p.persist_total != 0 && !p.sk_out && !p.nphase) {          // persistent: one workgroup per CU (LDS: one resident), XCD x walks entries [x * total / 8 ...)
         const unsigned total = grid.x * grid.y;
         kp.persist_total = (int)total;
         grid = dim3(total < 256u ? (total + 7u) & ~7u : 256u, 1);

@@ -307,7 +307,8 @@ bool vol32_xf() { static const bool on = [] { const char* s = getenv("CANONSWAP_
 // Launch one convolution on conv_halo (LDS-staged input patch, register-streamed weights).
 int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
 {
-    const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W;
+    const int nph = c.p.nphase > 0 ? c.p.nphase : 1;      // grouped launch (ConvParams::nphase): macs_per_pos is one phase's
+    const double fl = 2.0 * c.macs_per_pos * (double)c.p.N * c.p.D * c.p.H * c.p.W * nph;
     e->flops += fl;
     // MFMA work actually issued: packed (padded) channel counts and the taps this launch really runs
     {
@@ -316,7 +317,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const int NT = c.p.KD * c.p.KH * c.p.KW, PK = c.p.KW > 1 ? c.p.KW : c.p.KH;
             ksteps -= NT - (NT / PK) * (PK / 2 + PK % 2);
         }
-        e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps;
+        e->flops_exec += 2.0 * (double)c.p.N * c.p.D * c.p.H * c.p.W * c.p.Cout_pad * 32.0 * ksteps * nph;
     }
     // the 3x3x3 32 -> 32 convolutions of the feature volume run on their own kernel (vol32.hip; CANONSWAP_VOL32=0: A/B knob, conv_halo)
     // (below three frames the strips of a launch cover a quarter of the CUs or less: the plain convs - bit-identical on either kernel - stay
@@ -380,7 +381,7 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
             const int nck = (c.p.Cin + ck - 1) / ck;
             const long mtot = (long)c.p.N * c.p.D * c.p.H * c.p.W;
             const bool plain = c.mode == MODE_STD && !c.p.res.p && !c.p.pixscale && !c.p.out1.p && !c.p.stat_out && !c.p.s2 &&
-                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0 && !c.p.spmul &&
+                               c.p.act0 <= ACT_SIGMOID && c.p.out0.p && hcfg != CFG_H_SK128x32 && c.p.Cout % 4 == 0 && !c.p.spmul && !c.p.nphase &&
                                (!c.p.pool_hw || (!c.p.out0_f32 && !(c.p.H & 1) && !(c.p.W & 1)));      // (pooled: the finishing launch averages)
             constexpr int sk_maxwg = 64, sk_fill = 512;      // r02 sweep
             if (sk_on && plain && wgs <= sk_maxwg && nck >= 4 && e->sk_buf) {
@@ -573,16 +574,38 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         if (i >= 3) {
             // the nearest (1,2,2) up-sampling makes the three row / column taps read two source rows / columns: one 3x2x2 conv per
             // output phase (y, x) = (2i + a, 2j + b) on the source grid, 12 of 27 taps (pack.upsampled_conv3d_phases)
+            // The four phases differ in their weights, their leading padding and their offset into the output only: ONE launch, blockIdx.z =
+            // phase (ConvParams::nphase).  One frame: 128 / 256 workgroups that run their whole K loop instead of four split-K launches of
+            // 32 / 64 tiles each with a finishing launch behind it (8 launches of 14 + 7 us per level: profiles/r05_l_phase_group.txt); the
+            // same bits as four launches at every batch size (tests/test_gpu_ops.py).
             const int lwo = lw[lv - 1];
+            static const bool grouped = [] { const char* s = getenv("CANONSWAP_PHASE_GROUP"); return !s || atoi(s) != 0; }();      // =0: four launches (tests: same bits)
+            if (!grouped) {
+                for (int ab = 0; ab < 4; ++ab) {
+                    const int a = ab >> 1, b = ab & 1;
+                    ConvCall q1 = mk(e->w_dec_p[i - 3][ab], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
+                    q1.p.PH = a == 0; q1.p.PW = b == 0;
+                    q1.p.act0 = ACT_RELU;
+                    q1.p.out0 = td(e->dm_l[lv - 1] + ((long)a * S + b) * lwo, (long)FD * S * S * lwo, (long)S * S * lwo, 2L * S * lwo, 2L * lwo);
+                    if (i == 4) { q1.hcfg = CFG_H_256x32; TRY(go(e, q1, st, 4, 4)); }
+                    else TRY(go(e, q1, st));
+                }
+                continue;
+            }
+            ConvCall q = mk(e->w_dec_p[i - 3][0], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
+            q.p.act0 = ACT_RELU;
+            q.p.out0 = td(e->dm_l[lv - 1], (long)FD * S * S * lwo, (long)S * S * lwo, 2L * S * lwo, 2L * lwo);
+            q.p.nphase = 4;
             for (int ab = 0; ab < 4; ++ab) {
                 const int a = ab >> 1, b = ab & 1;
-                ConvCall q = mk(e->w_dec_p[i - 3][ab], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
-                q.p.PH = a == 0; q.p.PW = b == 0;
-                q.p.act0 = ACT_RELU;
-                q.p.out0 = td(e->dm_l[lv - 1] + ((long)a * S + b) * lwo, (long)FD * S * S * lwo, (long)S * S * lwo, 2L * S * lwo, 2L * lwo);
-                if (i == 4) { q.hcfg = CFG_H_256x32; TRY(go(e, q, st, 4, 4)); }     // 32 output channels: 256-position tile
-                else TRY(go(e, q, st));
+                q.p.ph_wofs[ab] = (long)(((intptr_t)e->w_dec_p[i - 3][ab].w - (intptr_t)e->w_dec_p[i - 3][0].w) / (intptr_t)sizeof(half_t));
+                q.p.ph_ooff[ab] = (unsigned)(((long)a * S + b) * lwo);
+                q.p.ph_PH[ab] = a == 0; q.p.ph_PW[ab] = b == 0;
             }
+            q.p.PH = 1; q.p.PW = 1;
+            q.name = i == 3 ? "W.dec3.p" : "W.dec4.p";
+            if (i == 4) { q.hcfg = CFG_H_256x32; TRY(go(e, q, st, 4, 4)); }     // 32 output channels: 256-position tile
+            else TRY(go(e, q, st));
             continue;
         }
         if (i == 4) { c.hcfg = CFG_H_256x32; TRY(go(e, c, st, 4, 4)); continue; }
