@@ -914,16 +914,38 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
     TRY(go(e, s64, st));
     // mlp_shared of the up blocks reads seg nearest-resized to 128 / 256 (util.py:297-298): run per output row phase on the 64x64
     // source grid and per group of column phases (pack.upsampled_conv_phases): 16/36 and 36/144 of the taps, same result
+    // Phases with the same taps and channel count differ in their weights, their leading padding and their output offset only: up to four
+    // of them per launch (ConvParams::nphase) - 16 phase convs in 5 launches (4 | 4 + 2 + 4 + 2); at one frame a phase alone is 96 workgroups.
+    static const bool sh_grouped = [] { const char* s = getenv("CANONSWAP_PHASE_GROUP"); return !s || atoi(s) != 0; }();      // =0: one launch per phase (tests: same bits)
     for (int lv = 0; lv < 2; ++lv) {
         const int sc = lv ? 4 : 2, S = 64 * sc;
         half_t* dst = lv ? e->g_a256 : e->g_a128;
+        bool done[16] = {};
         for (int k = 0; k < e->g_nshp[lv]; ++k) {
+            if (done[k]) continue;
             const cs_engine::ShPhase& P = e->g_shp[lv][k];
             ConvCall c = mk(P.conv, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
             c.p.PH = P.ph; c.p.PW = P.pw;
             c.p.act0 = ACT_RELU;
             // output pixel (sc*i + a, sc*j + b0 + k), channel c  <-  source position (i, j), channel k*384 + c
-            c.p.out0 = td(dst + ((long)P.a * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+            if (!sh_grouped) {
+                c.p.out0 = td(dst + ((long)P.a * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+                TRY(go(e, c, st));
+                continue;
+            }
+            c.p.out0 = td(dst, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+            int n = 0;
+            for (int j = k; j < e->g_nshp[lv] && n < 4; ++j) {
+                const cs_engine::ShPhase& Q = e->g_shp[lv][j];
+                if (done[j] || Q.conv.KH != P.conv.KH || Q.conv.KW != P.conv.KW || Q.conv.Cout_pad != P.conv.Cout_pad) continue;
+                done[j] = true;
+                c.p.ph_wofs[n] = (long)(((intptr_t)Q.conv.w - (intptr_t)P.conv.w) / (intptr_t)sizeof(half_t));
+                c.p.ph_ooff[n] = (unsigned)(((long)Q.a * S + Q.b0) * 384);
+                c.p.ph_PH[n] = Q.ph; c.p.ph_PW[n] = Q.pw;
+                if (Q.conv.b != P.conv.b && Q.conv.macs_per_pos != P.conv.macs_per_pos) { cs_set_error("G.shared: phases of one group differ in more than weights / padding / offset"); return -1; }
+                ++n;
+            }
+            c.p.nphase = n;
             TRY(go(e, c, st));
         }
     }
