@@ -101,6 +101,16 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
 
     // ---- this workgroup's item list: channel block cb (fixed), tiles xcd * t8 + tgi + tg * j
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+#ifdef W_ORDER_CB      /* A/B build: an XCD owns ONE channel block - its weights (2.4 MB of T's 9.4) stay in that L2 - and a share of the tiles */
+    const int cblk = xcd % s.ncb, part = xcd / s.ncb;
+    const int tp = (s.ntiles + (8 / s.ncb) - 1) / (8 / s.ncb);
+    const int n0 = cblk * 256;
+    auto tile_of = [&](int j) -> int {              // -1: no such item
+        const int r = slot + 32 * j;
+        const int t = part * tp + r;
+        return (r < tp && t < s.ntiles) ? t : -1;
+    };
+#else
     const int cblk = slot % s.ncb, tgi = slot / s.ncb;
     const int n0 = cblk * 256;
     auto tile_of = [&](int j) -> int {              // -1: no such item
@@ -108,6 +118,7 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(const ConvParams p, c
         const int t = xcd * s.t8 + r;
         return (r < s.t8 && t < s.ntiles) ? t : -1;
     };
+#endif
 
     const int isH = (int)p.in_sH, isW = (int)p.in_sW;
     // ---- halo staging: piece q = tid + 256 * j of a chunk <-> (voxel q / 10, slot q % 10); global -> LDS directly, pad slots are not fetched

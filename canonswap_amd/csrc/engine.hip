@@ -273,7 +273,6 @@ int pick_halo_cfg(const ConvParams& p, int mode)
         (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     // ... and, since the round-2 epilogue / addressing work, for the other 3x3 convs with 256 or more output channels (G 512->512 with
     // and without statistics, R's 512-channel pair, W.third): +0.7 % on the step, the same per-64-position statistics, the same bits
-    // (CANONSWAP_G256=0: the 128x128 tiles; 1: only the convs without statistics)
     if (mode == MODE_SPADE && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 && p.W >= 16 && p.H >= 8 && p.Cin % 64 == 0 &&
         (long)p.N * p.H * p.W >= 3 * 4096) return CFG_H_128x256;
     if ((mode == MODE_STD || mode == MODE_STDSTAT) && Cout_pad % 256 == 0 && p.KD == 1 && p.KH == 3 && p.KW == 3 &&
@@ -345,9 +344,8 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
     }
     // single-frame mode: the 512-channel 3x3 layers at 64 x 64 (T blend, G_middle / up_0, R's 2-D pair, W.third) on conv_lat.hip - the 16 x 8 tile
     // with its K loop split over the three kernel rows across 12 waves - while the launch is one workgroup per CU or less.  Another summation
-    // order than the batched path: only behind cs_set_latency_mode (CANONSWAP_LAT=0: A/B knob, conv_halo's four-wave tiles)
-    static const int lat_on = [] { const char* s = getenv("CANONSWAP_LAT"); return s ? atoi(s) : 1; }();
-    if (lat_on && e->latency_mode && c.hcfg < 0 && conv_lat_supported(c.p, c.mode) &&
+    // order than the batched path: only behind cs_set_latency_mode (conv_halo's four-wave tiles: 4.55 against 4.29 ms per frame, profiles/r05_e_ab_lat_ring.txt)
+    if (e->latency_mode && c.hcfg < 0 && conv_lat_supported(c.p, c.mode) &&
         (long)c.p.N * (c.p.H / 8) * (c.p.W / 16) * (c.p.Cout_pad / (c.mode == MODE_TBLEND ? 128 : 64)) <= 256) {
         c.stat_nblk = (c.p.W / 16) * (c.p.H / 8) * 2;      // partial-statistics blocks per sample: 64 positions each, in the 16 x 8 tiles' order
         TRY(e->run(0, st, [&] { return launch_conv_lat(c.p, c.mode, st); }, c.name, fl));

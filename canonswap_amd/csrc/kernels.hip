@@ -964,104 +964,10 @@ __global__ void __launch_bounds__(256, 4) t_mask_kernel(const half_t* __restrict
     }
 }
 
-// The same layer with vertical reuse: a wave owns RH output rows of a 16-column segment and marches down its RH + 2 input rows; every
-// fetched 16 bytes feed nine dot products (three output rows x three columns) instead of three, so the L1 / L2 read per output drops from
-// 3 x 18 / 16 = 3.4 KiB to (RH + 2) / RH x 18 / 16 = 1.4 KiB (RH = 8) - t_mask_kernel streams 0.27 GB of input per launch out of the L2
-// 3.4 times and ran at that rate (86 us per 64-frame launch = 10.5 TB/s of L2 reads).  The next input row (18 loads) is in flight while
-// the current one is consumed.  Per output the nine taps arrive kh-major (input row by input row), kw ascending within a row - another
-// fixed order than t_mask_kernel's; the lanes' partial sums are reduced exactly as there.
-template <int RH>
-__global__ void __launch_bounds__(256, 2) t_mask_rows_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp, const float* __restrict__ bias,
-                                                             float* __restrict__ tmask, int N, int H, int W)
-{
-    constexpr int SEG = 16, RS = 65, NCOL = SEG + 2;
-    __shared__ float part[4][SEG * RS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nseg = W / SEG, nhb = H / RH;
-    long blk = blockIdx.x;
-    if ((gridDim.x & 7) == 0) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // XCD x: a contiguous range of items
-    const long item = blk * 4 + wave;
-    const int sg = (int)(item % nseg); long r = item / nseg;
-    const int h0 = (int)(r % nhb) * RH;
-    const int n = (int)(r / nhb);
-    const int w0 = sg * SEG;
-    uint4 wt[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = *(const uint4*)(wp + ((long)((lane >> 2) * 9 + t) * 16) * 32 + (lane & 3) * 8);
-    const half_t* xb = x + (long)n * H * W * 512 + lane * 8;
-    const bool lok = w0 > 0, rok = w0 + SEG < W;
-    // input column c (w0 - 1 + c) of a row inside the map; the two columns that may lie outside the map are fetched from a valid address and
-    // replaced by zeros where they are used
-    auto fetch1 = [&](int row, int c) -> uint4 {
-        const int wq = (c == 0 && !lok) ? w0 : ((c == NCOL - 1 && !rok) ? w0 : w0 - 1 + c);
-        return *(const uint4*)(xb + ((long)row * W + wq) * 512);
-    };
-    // accumulators of the three output rows an input row reaches: aT = row r - 1 (complete after input row r), aM = row r, aB = row r + 1
-    float aT[SEG], aM[SEG], aB[SEG];
-#pragma unroll
-    for (int o = 0; o < SEG; ++o) { aT[o] = 0.f; aM[o] = 0.f; aB[o] = 0.f; }
-    // ONE row buffer: column c of the next input row is fetched into cur[c] right behind the last use of column c of this row, a whole row
-    // of dot products (648 per lane) ahead of its own first use
-    uint4 cur[NCOL];
-    {
-        const int row = h0 > 0 ? h0 - 1 : 0;
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) cur[c] = fetch1(row, c);
-    }
-    const int o_l = lane >> 2, q_l = lane & 3;
-    const float b0 = bias[0];
-    auto step = [&](int rr, auto load_t) {
-        constexpr bool LOAD = decltype(load_t)::value;
-        const int row = h0 + rr;
-        const bool live = row >= 0 && row < H;               // an input row outside the map contributes nothing
-        const int nrow = row + 1 < H ? row + 1 : H - 1;      // (behind the map's last row: a redundant fetch, never used)
-#pragma unroll
-        for (int c = 0; c < NCOL; ++c) {
-            const bool keep = live && !(c == 0 && !lok) && !(c == NCOL - 1 && !rok);
-            uint4 v;
-            v.x = keep ? cur[c].x : 0u; v.y = keep ? cur[c].y : 0u; v.z = keep ? cur[c].z : 0u; v.w = keep ? cur[c].w : 0u;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                // input column w0 - 1 + c is tap kw of output column w0 + c - kw
-                if (c - kw >= 0 && c - kw < SEG) {
-                    aB[c - kw] = tm_dot8(v, wt[0 * 3 + kw], aB[c - kw]);
-                    aM[c - kw] = tm_dot8(v, wt[1 * 3 + kw], aM[c - kw]);
-                    aT[c - kw] = tm_dot8(v, wt[2 * 3 + kw], aT[c - kw]);
-                }
-            }
-            if constexpr (LOAD) cur[c] = fetch1(nrow, c);
-        }
-        if (rr >= 1) {                                       // output row h0 + rr - 1 is complete
-#pragma unroll
-            for (int o = 0; o < SEG; ++o) part[wave][o * RS + lane] = aT[o];
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own LDS writes (no other wave reads them)
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum += part[wave][o_l * RS + q_l * 16 + i];
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            if (q_l == 0) tmask[(((long)n * H + row - 1) * W + w0 + o_l) * 4] = 1.f / (1.f + __expf(-(sum + b0)));
-        }
-#pragma unroll
-        for (int o = 0; o < SEG; ++o) { aT[o] = aM[o]; aM[o] = aB[o]; aB[o] = 0.f; }
-    };
-    for (int rr = -1; rr < RH; ++rr) step(rr, std::true_type{});
-    step(RH, std::false_type{});
-}
-
 int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, float* tmask, int N, int H, int W, hipStream_t st)
 {
-    // (which kernel runs depends on the map's shape only, never on N: a sample's bits do not depend on the batch it is in)
-    // Off by default: 86 -> 75 us per 64-frame launch (+0.13 % on the step), but one frame alone is 32 waves on this kernel against 256 on
-    // t_mask_kernel: +0.23 ms (3.7 %) on the single-frame step (profiles/r04_z_lat_knobs.txt) - and the choice cannot depend on N.
-    static const int rows_on = [] { const char* s = getenv("CANONSWAP_TMASK_ROWS"); return s ? atoi(s) : 0; }();
-    if (rows_on && H % 8 == 0 && W % 16 == 0 && ((H / 8) * (W / 16)) % 4 == 0 && !((uintptr_t)x & 15) && !((uintptr_t)wpacked & 15)) {
-        const long items = (long)N * (H / (rows_on == 4 ? 4 : 8)) * (W / 16);
-        if (rows_on == 4) hipLaunchKernelGGL(t_mask_rows_kernel<4>, dim3((unsigned)(items / 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
-        else hipLaunchKernelGGL(t_mask_rows_kernel<8>, dim3((unsigned)(items / 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
-        LAUNCH_CHECK("t_mask_rows");
-        return 0;
-    }
+    // (a row-marching variant - a wave owns 8 output rows of a 16-column segment, every fetched 16 bytes feed nine dot products: 86 -> 75 us per
+    // 64-frame launch, but 32 waves for one frame - was built in round 4 and removed in round 5: profiles/HISTORY.md)
     if (W % 16 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)wpacked & 15)) { cs_set_error("t_mask: width a multiple of 16, 16-byte aligned tensors"); return -1; }
     const long items = (long)N * H * (W / 16);
     if (items % 4 != 0) { cs_set_error("t_mask: N * H * W / 16 must be a multiple of 4"); return -1; }

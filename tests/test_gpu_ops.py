@@ -181,23 +181,6 @@ def test_conv_spade(xshift, kern):
     assert ops.rel_err(_from_cl(out)[:, :, 0], ref) < 3e-3
 
 
-def test_t_mask_row_marching_kernel_in_a_subprocess():
-    """t_mask_rows_kernel (CANONSWAP_TMASK_ROWS=8; off by default: slower on a single frame) against torch: the knob is read once per process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = f"""
-import sys
-sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
-import test_gpu_ops as t
-for a in ((2, 64, 64), (3, 16, 32)):
-    t.test_t_mask_valu_kernel(*a)
-print("rows ok")
-"""
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "CANONSWAP_TMASK_ROWS": "8"}, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "rows ok" in r.stdout, r.stderr[-2000:]
-
 
 @pytest.mark.parametrize("cfg,Cc,ep_general", [(17, 256, False), (17, 256, True), (10, 128, False)])
 @pytest.mark.parametrize("xshift", [0, 1])
