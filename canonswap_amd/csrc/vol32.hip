@@ -260,24 +260,25 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
         // outside the volume fetch a valid address of their own sample (first row and column of the strip) and are zeroed after the
         // transform; their write-back goes to the zero page - as zeros.
         const unsigned xsafe = (unsigned)(n * p.xy_sN + w0 * p.xy_sW + h0 * p.xy_sH + ((tid >> 2) & 15) * 32 + xq * 8);
-        auto xf_load = [&](int r, int it) {       // raw piece it of row r -> registers
+        auto xf_load_to = [&](int r, int it, float4 (&dr)[2], float4 (&ds)[2]) {       // raw piece it of row r -> registers
             if constexpr (XF != 0) {
                 const bool okl = xcok[it] && (unsigned)r < (unsigned)p.H && r <= h1;
                 const unsigned o = okl ? (unsigned)(xoff[it] + r * p.xy_sH) : xsafe;
                 const float* y = p.xf_y + o;
-                xr[it][0] = *(const float4*)y; xr[it][1] = *(const float4*)(y + 4);
+                dr[0] = *(const float4*)y; dr[1] = *(const float4*)(y + 4);
                 if constexpr (XRES) {
                     const float* x = p.xf_res + o;
-                    xs[it][0] = *(const float4*)x; xs[it][1] = *(const float4*)(x + 4);
+                    ds[0] = *(const float4*)x; ds[1] = *(const float4*)(x + 4);
                 }
             }
         };
+        auto xf_load = [&](int r, int it) { xf_load_to(r, it, xr[it], xs[XRES ? it : 0]); };
         // part 0 / 1: the transform of channels 0..3 / 4..7 of the piece; part 2: split, ds_writes [, write-back]; part < 0: all of it.  In the
         // K loop the three parts of a piece go into three consecutive MFMA groups: a wave issues about three VALU instructions in the
         // shadow of one MFMA (one wave per SIMD), a whole piece (~110 instructions) inside one group of 12 MFMAs left the matrix pipe idle
         // for half of it.
         float xa[8];
-        auto xf_write = [&](int r, int slot, int it, int part) {     // registers -> transform -> [hi | lo] images of ring slot `slot`
+        auto xf_write_from = [&](int r, int slot, int it, int part, const float4 (&xr)[2], const float4 (&xs)[2]) {     // registers -> transform -> [hi | lo] images of ring slot `slot`
             if constexpr (XF != 0) {
                 int idx = it * 256 + tid;
                 if (idx >= V_NC * 64) idx -= 128;
@@ -285,8 +286,8 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (part >= 0 && (k >> 2) != part) continue;
-                    const float v = ((const float*)&xr[it][k >> 2])[k & 3];
-                    if constexpr (XRES) xa[k] = gn_lrelu(v, xsc[k], xsh[k], ((const float*)&xs[it][k >> 2])[k & 3], p.xf_slope);
+                    const float v = ((const float*)&xr[k >> 2])[k & 3];
+                    if constexpr (XRES) xa[k] = gn_lrelu(v, xsc[k], xsh[k], ((const float*)&xs[k >> 2])[k & 3], p.xf_slope);
                     else if constexpr (XF >= 2) xa[k] = gn_lrelu(v, xsc[k], xsh[k], 0.f, p.xf_slope);
                     else xa[k] = v;
                     if (!ok) xa[k] = 0.f;                // zero padding applies to the conv's input, i.e. after the transform
@@ -305,15 +306,21 @@ __global__ void __launch_bounds__(256, 1) vol32_kernel(const Vol32Params p)
                 }
             }
         };
+        auto xf_write = [&](int r, int slot, int it, int part) { xf_write_from(r, slot, it, part, xr[it], xs[XRES ? it : 0]); };
         if constexpr (XF != 0) {
             // rows h0 - 1, h0, h0 + 1 into slots 0 .. 2 (row h + 2 is fetched, transformed and written within step h: no load result is
-            // carried over the loop's back-edge, where hipcc would drain vmcnt to 0 - the step's own stores included - at every step)
-            for (int i = 0; i < 3; ++i) {
+            // carried over the loop's back-edge, where hipcc would drain vmcnt to 0 - the step's own stores included - at every step).
+            // All nine pieces are fetched before the first is converted: one round trip instead of three (a 2-row item of the one-frame launch
+            // is mostly this prologue)
+            float4 pr[3][3][2], ps[XRES ? 3 : 1][3][2];
 #pragma unroll
-                for (int it = 0; it < 3; ++it) xf_load(h0 - 1 + i, it);
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int it = 0; it < 3; ++it) xf_write(h0 - 1 + i, i, it, -1);
-            }
+                for (int it = 0; it < 3; ++it) xf_load_to(h0 - 1 + i, it, pr[i][it], ps[XRES ? i : 0][it]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int it = 0; it < 3; ++it) xf_write_from(h0 - 1 + i, i, it, -1, pr[i][it], ps[XRES ? i : 0][it]);
         } else {
             // row h0 - 1 + i lives in slot i (mod RING) of this item
 #pragma unroll
