@@ -1,6 +1,7 @@
-"""Single-frame latency mode (BASELINE configs[1]): cross-workgroup split-K for launches that cannot fill the chip.
-Same tolerance as the batched path (PSNR >= 50 dB vs the oracle), deterministic, and close to - not bit-identical with - the
-batched path (another summation order, which is why it is a mode)."""
+"""Single-frame latency mode (BASELINE configs[1]): forms that only pay when a launch cannot fill the chip and that add an output
+element's products in another order than the batched path - conv_lat (the K loop of the 512-channel 3x3 convs split over twelve waves of a workgroup),
+cross-workgroup split-K for the deep hourglass levels, 2-row statistics blocks in R's volume convs.  Same tolerance as the batched path (PSNR >= 50 dB
+vs the oracle), deterministic, and close to - not bit-identical with - the batched path, which is why it is a mode."""
 import numpy as np
 import pytest
 import torch
