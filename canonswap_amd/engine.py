@@ -31,7 +31,7 @@ class Engine:
         _lib.check(self.lib.cs_create(device_id, max_batch, C.byref(h)), "cs_create")
         self.h = h
         self.latency_mode = bool(latency_mode)
-        if latency_mode:         # BASELINE configs[1]: split-K for launches that cannot fill the chip (see cs_set_latency_mode)
+        if latency_mode:         # BASELINE configs[1]: the one-frame forms (conv_lat, split-K, 2-row volume segments; see cs_set_latency_mode)
             _lib.check(self.lib.cs_set_latency_mode(h, 1), "cs_set_latency_mode")
         self._ids = []            # resident identities: [slot, device copy (512,), last tensor seen, its _version, use tick]
         self._tick = 0
