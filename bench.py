@@ -307,7 +307,7 @@ def main():
     cpu, parity = None, None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import canonswap_ref as O          # cpu_baseline leg: the oracle timed on this node's host cores
-        cores = min(os.cpu_count() or 1, 32)           # threads used ("cores"); more than 32 slows PyTorch-CPU down on this path
+        cores = min(os.cpu_count() or 1, 16)           # threads used ("cores"): the fastest count on the GPU box's host (profiles/r05_r_cpu_threads.txt: 0.59 frames/s at 16, 0.45 at 32, 0.14 at 128 of 256 cores)
         torch.set_num_threads(cores)
         # parity of THIS binary in THIS run: first and last frame of the first launch (step 0) against the fp32 oracle
         from canonswap_amd import pack
