@@ -139,7 +139,8 @@ typedef struct cs_conv_desc {
     const float* stats;       /* SPADE: [N][C][2] = (mean, 1/sqrt(var+eps)) from cs_op_chan_stats */
     int mode;                 /* 0 std, 1 T blend, 2 SPADE, 3 pixel-shuffle + sigmoid, 5 std with out0 = act0(IN(res) * (1 + conv + bias)): SPADE's
                                  modulation without the beta half (res fp16, stats as for SPADE; /root/reference/src/modules/util.py:295-302) */
-    int cfg;                  /* -2 auto conv_halo, 10..20 conv_halo tile cfg, 30 the vol32 kernel (3x3x3 32 -> 32 on [N][H][W][16][32]); -1, 0..3: test-only library */
+    int cfg;                  /* -2 auto conv_halo, 10..20 conv_halo tile cfg, 30 the vol32 kernel (3x3x3 32 -> 32 on [N][H][W][16][32]), 31 conv_wide, 32 conv_lat
+                               * (both: 3x3, 2-D, the engine's tensor combinations; conv_lat: Cin = 512, another summation order); -1, 0..3: test-only library */
     int tile_w, tile_h;       /* 0 = auto */
     int ck;                   /* conv_halo channel chunk: 0 auto, 32 or 64 */
     int xcd_map;              /* conv_halo workgroup -> tile mapping: 0 engine default, k > 0 forces mapping k - 1 (common.h) */
