@@ -108,15 +108,16 @@ def grid_sample(inp_hwdc, grid):
     return out32, out16
 
 
-def chan_stats(x, eps=1e-5):
-    """x: [N, P, C] fp16/fp32 contiguous -> [N, C, 2] = (mean, 1/sqrt(var + eps)), biased variance."""
+def chan_stats(x, eps=1e-5, with_partials=False):
+    """x: [N, P, C] fp16/fp32 contiguous -> [N, C, 2] = (mean, 1/sqrt(var + eps)), biased variance
+    (with_partials: also the first pass's partial sums [N, blocks, C, 2])."""
     lib = _lib.load()
     N, P, Cc = x.shape
     stats = torch.zeros(N, Cc, 2, dtype=torch.float32, device=x.device)
     part = torch.empty(lib.cs_op_chan_stats_partial_floats(N, P, Cc), dtype=torch.float32, device=x.device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.cs_op_chan_stats(_p(x), int(x.dtype == torch.float32), N, P, Cc, eps, _p(part), _p(stats), st), "cs_op_chan_stats")
-    return stats
+    return (stats, part.view(N, -1, Cc, 2)) if with_partials else stats
 
 
 def rel_err(a, b):

@@ -292,6 +292,34 @@ def test_chan_stats(dtype, Cc, P):
     assert torch.allclose(st[..., 1].double(), 1.0 / torch.sqrt(xf.var(1, unbiased=False) + 1e-5), rtol=1e-4)
 
 
+@pytest.mark.parametrize("Cc,P", [(512, 4096), (32, 65536), (64, 1000)])
+def test_chan_stats_finish_matches_a_numpy_emulation_of_its_order(Cc, P):
+    """chan_stats_finish_kernel: block lane bl (0 .. 63) adds the partial blocks bl, bl + 64, ... in ascending order in fp64, then a pairwise tree over
+    the 64 lanes, mean / variance in fp64, one rounding to fp32.  Emulated here from the first pass's partials: equal bit for bit - which pins the order
+    independently of how the kernel maps lanes to threads (round 5 changed that mapping, not the order)."""
+    import hip_ops as ops
+    r = _rng(181)
+    N = 3
+    x = (_randn(r, N, P, Cc) + 0.3).half()
+    st, part = ops.chan_stats(x.to(DEV), with_partials=True)
+    torch.cuda.synchronize()
+    part = part.cpu().numpy().astype(np.float64)                         # [N, nblk, C, 2]
+    nblk = part.shape[1]
+    lanes = np.zeros((N, 64, Cc, 2))
+    for bl in range(64):
+        for b in range(bl, nblk, 64):
+            lanes[:, bl] = lanes[:, bl] + part[:, b]
+    o = 32
+    while o > 0:
+        lanes[:, :o] = lanes[:, :o] + lanes[:, o:2 * o]
+        o >>= 1
+    s, ss = lanes[:, 0, :, 0], lanes[:, 0, :, 1]
+    mean = s * (1.0 / P)
+    var = np.maximum(ss * (1.0 / P) - mean * mean, 0.0)
+    want = np.stack([mean.astype(np.float32), (1.0 / np.sqrt(var + float(np.float32(1e-5)))).astype(np.float32)], axis=-1)
+    assert np.array_equal(st.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("xmap", [1, 2])
 @pytest.mark.parametrize("shape", ["2d_multi_cblk", "3d_v32", "2d_odd_tiles"])
 def test_conv_xcd_map_bit_equal(xmap, shape):
