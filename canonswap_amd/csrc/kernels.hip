@@ -223,16 +223,10 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
         for (int c8 = 0; c8 < 8; ++c8)
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = fmaf(wv[c8], (float)cv[c8][j], a[j]);
-        // the slot's five fp16 values as three LDS stores instead of five (slot k starts at byte 10 k of the row: 4-byte aligned for even k)
-        {
-            const half_t h0 = (half_t)heat, h1 = (half_t)a[0], h2 = (half_t)a[1], h3 = (half_t)a[2], h4 = (half_t)a[3];
-            typedef _Float16 dm_h2_t __attribute__((ext_vector_type(2)));
-            if ((k & 1) == 0) {       // wave-uniform
-                *(dm_h2_t*)o = (dm_h2_t){h0, h1}; *(dm_h2_t*)(o + 2) = (dm_h2_t){h2, h3}; o[4] = h4;
-            } else {
-                o[0] = h0; *(dm_h2_t*)(o + 1) = (dm_h2_t){h1, h2}; *(dm_h2_t*)(o + 3) = (dm_h2_t){h3, h4};
-            }
-        }
+        o[0] = (half_t)heat;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[1 + j] = (half_t)a[j];      // (packed as three 4-byte stores hipcc folds the last fma of a[j] into the fp16 conversion -
+                                                                  // one rounding instead of two, other bits - for no measurable time: five 2-byte stores stay)
     }
     __syncthreads();
     for (int q = t; q < W * 14; q += 256) {                  // 14 pieces of 16 bytes per voxel
@@ -614,34 +608,25 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const void* __restrict_
 __global__ void __launch_bounds__(256) chan_stats_finish_kernel(const float* __restrict__ partials, int nblk, int C, int NC, double cnt_inv,
                                                                 float eps, float* __restrict__ stats)
 {
-    // Fixed-order fp64 reduction -> deterministic: "block lane" bl (0 .. 63) adds the partial blocks b = bl, bl + 64, ... in ascending order, then a
-    // pairwise tree over the 64 lanes, the same shape every time.  A workgroup finishes 16 consecutive channels: thread (t, c) = (tid / 16, tid % 16)
-    // plays the four block lanes t, t + 16, t + 32, t + 48 of channel c, so the 16 threads of one t read 128 contiguous bytes per block (round 5: one
-    // full line per fetch instead of 32 bytes with four channels per workgroup: 12.9 -> ~7 us per launch at 64 frames; the same sums in the same order).
-    __shared__ double red[2][64][16];
-    const int c16 = threadIdx.x & 15, t = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + c16;      // (n, c) flat index, NC a multiple of 16
+    // workgroup = 4 channels x 64 lanes over the partials (the kernel is latency-bound: the deeper the fan-out over the partial
+    // blocks, the fewer dependent loads per thread); fixed-order fp64 reduction -> deterministic
+    __shared__ double red[2][64][4];
+    const int cl = threadIdx.x & 3, bl = threadIdx.x >> 2;
+    const int i = blockIdx.x * 4 + cl;       // (n, c) flat index, NC multiple of 4
     const int n = i / C, c = i % C;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int bl = t + 16 * j;
-        double s = 0, ss = 0;
-        for (int b = bl; b < nblk; b += 64) {
-            const float2 q = *(const float2*)(partials + (((long)n * nblk + b) * C + c) * 2);
-            s += q.x; ss += q.y;
-        }
-        red[0][bl][c16] = s; red[1][bl][c16] = ss;
+    double s = 0, ss = 0;
+    for (int b = bl; b < nblk; b += 64) {
+        const float2 q = *(const float2*)(partials + (((long)n * nblk + b) * C + c) * 2);
+        s += q.x; ss += q.y;
     }
+    red[0][bl][cl] = s; red[1][bl][cl] = ss;
     __syncthreads();
-    for (int o = 32; o > 0; o >>= 1) {       // pairwise tree over the 64 block lanes
-        for (int e = threadIdx.x; e < o * 16; e += 256) {
-            const int bl = e >> 4, cc = e & 15;
-            red[0][bl][cc] += red[0][bl + o][cc]; red[1][bl][cc] += red[1][bl + o][cc];
-        }
+    for (int o = 32; o > 0; o >>= 1) {       // pairwise tree over the 64 block lanes, same shape every time
+        if (bl < o) { red[0][bl][cl] += red[0][bl + o][cl]; red[1][bl][cl] += red[1][bl + o][cl]; }
         __syncthreads();
     }
-    if (t == 0) {
-        const double s = red[0][0][c16], ss = red[1][0][c16];
+    if (bl == 0) {
+        s = red[0][0][cl]; ss = red[1][0][cl];
         const double mean = s * cnt_inv;
         double var = ss * cnt_inv - mean * mean;
         if (var < 0) var = 0;
@@ -657,7 +642,7 @@ long chan_stats_partial_floats(int N, long P, int C) { return (long)N * cdiv(P, 
 int launch_chan_stats_finish(const float* partials, int nblk, int N, int C, double cnt_inv, float eps, float* stats, hipStream_t st)
 {
     if (C % 16) { cs_set_error("chan_stats_finish: unsupported C=%d", C); return -1; }
-    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 16)), dim3(256), 0, st, partials, nblk, C, N * C, cnt_inv, eps, stats);
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, partials, nblk, C, N * C, cnt_inv, eps, stats);
     LAUNCH_CHECK("chan_stats_finish");
     return 0;
 }
@@ -671,7 +656,7 @@ int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps
     if (is_f32) hipLaunchKernelGGL(chan_stats_kernel<true>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     else hipLaunchKernelGGL(chan_stats_kernel<false>, grid, dim3(256), 0, st, x, P, C, ppb, partials);
     LAUNCH_CHECK("chan_stats");
-    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 16)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
+    hipLaunchKernelGGL(chan_stats_finish_kernel, dim3((unsigned)((long)N * C / 4)), dim3(256), 0, st, partials, (int)grid.x, C, N * C,
                        1.0 / (double)P, eps, stats);
     LAUNCH_CHECK("chan_stats_finish");
     return 0;
