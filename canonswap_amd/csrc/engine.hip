@@ -280,8 +280,10 @@ int pick_halo_cfg(const ConvParams& p, int mode)
     if (Cout_pad % 128 == 0) {
         // a launch of 128 or fewer 128x128 workgroups leaves half of the 256 CUs idle (one frame: the 512-channel 3x3 convs at 64x64
         // are 32 x 4): 128x64 tiles put a workgroup on every CU.  Same K order per output element, same bits.
+        // (the 1x1 convs too - F.second, W.fourth, the learned shortcuts: 64 - 128 workgroups of two or four K-steps per chunk otherwise)
         const long tiles = ((long)p.N * p.D * p.H * p.W + 127) / 128;
-        if ((mode == MODE_STD || mode == MODE_STDSTAT) && p.KH == 3 && p.KW == 3 && tiles * (Cout_pad / 128) <= 128)
+        const bool k33 = p.KH == 3 && p.KW == 3, k11 = p.KD == 1 && p.KH == 1 && p.KW == 1 && mode == MODE_STD;
+        if ((mode == MODE_STD || mode == MODE_STDSTAT) && (k33 || k11) && tiles * (Cout_pad / 128) <= 128)
             return CFG_H_128x64;
         return CFG_H_128x128;
     }

@@ -1132,17 +1132,26 @@ __global__ void __launch_bounds__(256) splitk_finish_pool_kernel(const ConvParam
     const int h2 = (int)(r % H2); r /= H2;
     const int d = (int)(r % p.D); r /= p.D;
     float a[4][4];
+    const float* src[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long pos = ((r * p.D + d) * p.H + 2 * h2 + (j >> 1)) * p.W + 2 * w2 + (j & 1);
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < p.sk_splits; ++k) {
-            const float4 q = *(const float4*)(p.sk_out + ((long)k * mtot + pos) * p.Cout_pad + c);
-            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-        }
+        src[j] = p.sk_out + pos * p.Cout_pad + c;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[j][k] = act_f(v[k] + (p.bias ? p.bias[c + k] : 0.f), p.act0, p.slope0);
+        for (int k = 0; k < 4; ++k) a[j][k] = 0.f;
     }
+    // (splits outermost: the four window positions' fetches of a split go out together; per position the splits still add in split order)
+    for (int k = 0; k < p.sk_splits; ++k) {
+        float4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = *(const float4*)(src[j] + (long)k * mtot * p.Cout_pad);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j][0] += q[j].x; a[j][1] += q[j].y; a[j][2] += q[j].z; a[j][3] += q[j].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[j][k] = act_f(a[j][k] + (p.bias ? p.bias[c + k] : 0.f), p.act0, p.slope0);
     const long o = r * p.out0.sN + (long)d * p.out0.sD + (long)h2 * p.out0.sH + (long)w2 * p.out0.sW + c;
     h4_t x;
 #pragma unroll
