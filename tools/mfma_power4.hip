@@ -13,7 +13,7 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 
 // MF activation fragments (LDS) x NF weight fragments (global, L2-resident set; SHARE: wave pairs read the same fragments) per wave and K-step;
 // IMG: KB of LDS per workgroup (sets the occupancy together with the grid)
-template <int MF, int NF, bool LDS, bool L2, bool SHARE, int IMG, int OCC>
+template <int MF, int NF, bool LDS, bool L2, bool SHARE, int IMG, int OCC, bool BLDS = false>
 __global__ void __launch_bounds__(256, OCC) mix(const h8_t* __restrict__ adata, const h8_t* __restrict__ wdata, unsigned wmask, float* out, int iters)
 {
     constexpr int NI = IMG * 64;                   // h8_t elements
@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(256, OCC) mix(const h8_t* __restrict__ adata, 
         }
 #pragma unroll
         for (int n = 0; n < NF; ++n)
-            if (L2) bv[n] = wdata[(unsigned)(((s * NF + n) * 4 + wsel) * 64 + lane) & wmask];
+            if (BLDS) bv[n] = img[((s * NF + n + 777) * 64 + lane + wsel * 23) & (NI - 1)];      // weight fragments from LDS too (what a DMA-staged weight tile would cost to read)
+            else if (L2) bv[n] = wdata[(unsigned)(((s * NF + n) * 4 + wsel) * 64 + lane) & wmask];
             else if (s < 2) bv[n] = wdata[tid * NF + n];
     };
     fetch(0, a[0], b[0]);
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(256, OCC) mix(const h8_t* __restrict__ adata, 
     for (int it = 0; it < iters; it += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (LDS || L2 || (it == 0 && u == 0)) fetch(++s, a[u ^ 1], b[u ^ 1]);
+            if (LDS || L2 || BLDS || (it == 0 && u == 0)) fetch(++s, a[u ^ 1], b[u ^ 1]);
 #pragma unroll
             for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -81,6 +82,8 @@ int main(int argc, char** argv)
         {"128x256 tile (SPADE gamma / beta): 8x4 per wave, 8 lds + 4 l2 unshared, 2 per CU, 2 MB set", 8, 4, 512, 3},
         {"128x128 tile (hourglass enc / dec, 64-channel SPADE): 8x2 per wave, 8 lds + 2 l2 unshared, 3 per CU, 4 MB set", 8, 2, 768, 4},
         {"8x8 fragments (conv_wide): 8 lds + 8 l2 (pairs share), 1 per CU, 4 MB set", 8, 8, 256, 5},
+        {"8x8 fragments, BOTH operands from LDS (16 ds_read_b128 per 64 MFMAs), 1 per CU", 8, 8, 256, 6},
+        {"8x8 fragments, registers only", 8, 8, 256, 7},
     };
     for (const Case& c : cases) {
         int iters = 400; float ms = 0;
@@ -95,6 +98,8 @@ int main(int argc, char** argv)
             case 3: wm = (1u << 17) - 1; MIX(8, 4, true, true, false, 64, 2); break;
             case 4: MIX(8, 2, true, true, false, 32, 3); break;
             case 5: MIX(8, 8, true, true, true, 64, 1); break;
+            case 6: MIX(8, 8, true, false, true, 64, 1, true); break;
+            case 7: MIX(8, 8, false, false, false, 1, 1); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", c.name); break; }
