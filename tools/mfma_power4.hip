@@ -60,6 +60,64 @@ __global__ void __launch_bounds__(256, OCC) mix(const h8_t* __restrict__ adata, 
     out[blockIdx.x * 256 + tid] = r;
 }
 
+// conv_wide with its weights THROUGH LDS: per K-step a workgroup's four waves DMA the step's 16 weight fragments (16 KB, 4 pieces per wave,
+// global_load_lds from an L2-resident set) into a ring of three steps, wait for their own pieces of the step about to be read (counted vmcnt),
+// meet at a barrier, and every wave reads 8 activation + 8 weight fragments from LDS for its 64 MFMAs.
+__global__ void __launch_bounds__(256, 1) mixdma(const h8_t* __restrict__ adata, const h8_t* __restrict__ wdata, unsigned wmask, float* out, int iters)
+{
+    extern __shared__ h8_t dyn[];
+    h8_t* img = dyn;                               // 64 KB of activations
+    h8_t* ring = dyn + 4096;                       // 3 x 16 KB of weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4096; i += 256) img[i] = adata[((blockIdx.x & 63) * 4096 + i) & 262143];
+    __syncthreads();
+    f4_t acc[8][8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    // (the DMA goes through inline asm: hipcc waits with vmcnt(0) before any LDS read behind a DMA it knows of - DESIGN 5.6 rules 1 and 7)
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    i4_t rsrc;
+    {
+        const unsigned long long base = (unsigned long long)wdata;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)base);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu));
+        rsrc[2] = 0x7fffffff; rsrc[3] = 0x00020000;
+    }
+    const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) h8_t*)ring;
+    auto dma = [&](int s) {                        // this wave's 4 pieces of step s -> ring slot s % 3
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_ring + (unsigned)(((s % 3) * 16 + wave * 4 + q) * 1024)));
+            const unsigned voff = (((unsigned)((s * 16 + wave * 4 + q) * 64 + lane)) & wmask) * 16u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc) : "memory");
+        }
+    };
+    dma(0); dma(1);
+    for (int s = 0; s < iters; ++s) {
+        dma(s + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // the pieces of step s have landed (those of s + 1, s + 2 may be in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        h8_t a[8], b[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m] = img[((s * 8 + m) * 64 + lane + wave * 17) & 4095];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) b[n] = ring[((s % 3) * 16 + (wave >> 1) * 8 + n) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) MFMA(acc[m][n], a[m], b[n]);
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) r += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    out[blockIdx.x * 256 + tid] = r;
+}
+
 int main(int argc, char** argv)
 {
     const double secs = argc > 1 ? atof(argv[1]) : 1.0;
@@ -84,6 +142,7 @@ int main(int argc, char** argv)
         {"8x8 fragments (conv_wide): 8 lds + 8 l2 (pairs share), 1 per CU, 4 MB set", 8, 8, 256, 5},
         {"8x8 fragments, BOTH operands from LDS (16 ds_read_b128 per 64 MFMAs), 1 per CU", 8, 8, 256, 6},
         {"8x8 fragments, registers only", 8, 8, 256, 7},
+        {"8x8 fragments, weights DMA-staged into an LDS ring (16 KB per step and workgroup, barrier per step), 16 lds reads", 8, 8, 256, 8},
     };
     for (const Case& c : cases) {
         int iters = 400; float ms = 0;
@@ -100,6 +159,12 @@ int main(int argc, char** argv)
             case 5: MIX(8, 8, true, true, true, 64, 1); break;
             case 6: MIX(8, 8, true, false, true, 64, 1, true); break;
             case 7: MIX(8, 8, false, false, false, 1, 1); break;
+            case 8: {
+                static bool once = false;
+                if (!once) { hipFuncSetAttribute((const void*)mixdma, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 49152); once = true; }
+                hipLaunchKernelGGL(mixdma, dim3(c.nb), dim3(256), 65536 + 49152, 0, da, dw, wm, out, iters);
+                break;
+            }
             }
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
             if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", c.name); break; }
