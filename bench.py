@@ -68,6 +68,7 @@ def parse_args():
                          "parallel.stream_groups (4 streams on 8 GPUs: stream s on GPU pair {2s, 2s+1})")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fixed-job", action="store_true", help="skip the fixed-size job reported next to the weak-scaling figure")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call measurement (BASELINE configs[1], latency mode) reported next to the headline")
     ap.add_argument("--latency-mode", action="store_true",
                     help="BASELINE configs[1] (--batch 1): cross-workgroup split-K for the launches that cannot fill the chip")
     ap.add_argument("--identities", type=int, default=1,
@@ -162,6 +163,11 @@ def main():
             os.remove(shm)
     sw = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), packed_blobs=blobs, max_batch=B,
                      latency_mode=a.latency_mode)
+    # BASELINE configs[1] in the same line: a second engine of one frame in latency mode (N = 1 default run only; 0.5 GB of workspace)
+    single_on = (rank == 0 and world == 1 and not a.no_single_frame and not a.latency_mode and B > 1 and not a.streams and a.frames <= 0
+                 and not a.no_fixed_job and max(1, min(a.identities, 8)) == 1)
+    sw1 = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), packed_blobs=blobs, max_batch=1,
+                      latency_mode=True) if single_on else None
     del blobs
     eng = sw.engine
 
@@ -294,6 +300,34 @@ def main():
                      # efficiency against the same kind of job on one GPU = value_per_gpu / (the N = 1 line's fixed_job.value)
                      "value_per_gpu": round(fixed_T / fdt / world, 3)}
 
+    # ---- BASELINE configs[1]: one 512x512 frame per call, latency mode (cs_set_latency_mode: DESIGN 5.8), inputs resident, every call synchronous
+    # with the next only through the stream (the caller hands over frame after frame); 10 untimed + 200 timed calls
+    single, single_out = None, None
+    if sw1 is not None:
+        e1 = sw1.engine
+        e1.set_identity(sid[0:1], slot=0)
+        o1 = torch.empty(1, 512, 512, 3, dtype=torch.uint8, device=dev)
+        f1 = torch.empty(1, 3, 512, 512, dtype=torch.float32, device=dev)
+
+        def one(j, want_f32=False):
+            e1.swap_frames(pool["img"][j:j + 1], pool["x_t"][j:j + 1], pool["x_can"][j:j + 1], None, want_f32=want_f32, want_u8=True, out_u8=o1,
+                           out_f32=f1 if want_f32 else None, slots=[0])
+        for i in range(10):
+            one(i % P)
+        torch.cuda.synchronize(dev)
+        n1, t1 = 200, time.perf_counter()
+        for i in range(n1):
+            one((131 * i) % P)
+        torch.cuda.synchronize(dev)
+        d1 = time.perf_counter() - t1
+        one(0, want_f32=True)                                # pool frame 0 for the parity leg below
+        torch.cuda.synchronize(dev)
+        single_out = f1.cpu()
+        single = {"workload": "BASELINE configs[1]: one 512x512 frame per call on 1 GPU, latency mode (cs_set_latency_mode), inputs resident in HBM",
+                  "frames": n1, "ms_per_frame": round(d1 / n1 * 1e3, 3), "value": round(n1 / d1, 3), "unit": "frames/s",
+                  "conv_roofline_frac_end_to_end": round(ALGO_GFLOP_PER_FRAME * 1e9 * (n1 / d1) / (PEAK_TFLOPS_F16 * 1e12), 4)}
+        e1.close()
+
     # ---- roofline of the dominant kernel family (conv_halo_kernel): HIP events around every launch, same workload
     prof = None
     if rank == 0:
@@ -345,6 +379,10 @@ def main():
             worst = min(worst, O.psnr(o32[j:j + 1].cpu(), ref))
             d = out_u8[j:j + 1].cpu().numpy().astype(np.float64) - O.parse_output(ref).astype(np.float64)
             mad = max(mad, float(np.abs(d).mean()))
+        if single is not None:                              # the one-frame engine's pool frame 0 against the same oracle
+            with torch.no_grad():
+                ref0 = O.swap_frame(osd, *[torch.from_numpy(inp[key][0:1]) for key in ("img", "x_t", "x_can")], ids_cpu[0:1])["out"]
+            single["psnr_db_pool_frame_0"] = round(O.psnr(single_out, ref0), 2)
         parity = {"psnr_db_min": round(worst, 2), "u8_mean_abs_diff": round(mad, 4),
                   "parity_sample": f"pool frames {[int(idx[j]) for j in sorted(sample)]} in one {n}-frame launch vs the fp32 CPU oracle" +
                                    (f" (pool frame {worst_known}: the worst of the {wj.get('pool_frames', n)} surveyed in profiles/psnr_worst_frame.json)"
@@ -419,6 +457,8 @@ def main():
             line.update(parity)
         if fixed:
             line["fixed_job"] = fixed
+        if single:
+            line["single_frame"] = single
         if a.streams:
             per = []
             for s, g in enumerate(groups):
