@@ -196,6 +196,13 @@ def _isa_check_lat(obj_dir: str, objdump: str) -> dict:
             raise RuntimeError(f"isa_check: {name}: no MFMA")
         if any(l.startswith(("s_cbranch", "s_branch")) for l in body[mf[0]:mf[-1]]):
             raise RuntimeError(f"isa_check: {name}: a branch inside the K loop (the walk assumes straight-line code)")
+        # m0 belongs to the hidden DMA: `s_mov_b32 m0, sN` is legal only as the head of `s_mov_b32 m0 | s_nop | buffer_load ... lds`, and nothing else
+        # in the kernel may read or write it (a compiler that started to keep a value in m0 would be caught here)
+        for i, l in enumerate(body):
+            if re.search(r"\bm0\b", l):
+                ok = l.startswith("s_mov_b32 m0,") and any(b.startswith("buffer_load") and b.endswith("lds") for b in body[i + 1:i + 3])
+                if not ok:
+                    raise RuntimeError(f"isa_check: {name}: `{l}` touches m0 outside the hidden LDS-DMA sequence")
         nvm, open_dma, nbar, ndma = 0, [], 0, 0
         for i, l in enumerate(body[:mf[-1] + 1]):
             op = l.split()[0]

@@ -19,7 +19,9 @@ static inline int ep_check_extents(const ConvParams& p, const char* who)
     };
     auto wide = [&](const TDesc& t) { return t.sD >= (1L << 23) || t.sH >= (1L << 23) || t.sW >= (1L << 23); };
     const long lim = 1L << 31;
-    if ((p.out0.p && span(p.out0) >= lim) || (p.out1.p && span(p.out1) >= lim) || (p.res.p && span(p.res) >= lim)) {
+    long ph_max = 0;          // a grouped launch (ConvParams::nphase) adds its phase's element offset to every out0 address
+    for (int z = 0; z < p.nphase && z < 4; ++z) ph_max = p.ph_ooff[z] > ph_max ? (long)p.ph_ooff[z] : ph_max;
+    if ((p.out0.p && span(p.out0) + ph_max >= lim) || (p.out1.p && span(p.out1) >= lim) || (p.res.p && span(p.res) >= lim)) {
         cs_set_error("%s: a tensor of this launch spans 2^31 elements or more (32-bit in-tensor offsets)", who);
         return -1;
     }

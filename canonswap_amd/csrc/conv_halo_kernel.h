@@ -1232,6 +1232,10 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     }
     if (p.nphase) {
         if (SK || !halo_phase_group<WCH, ST>() || p.nphase < 1 || p.nphase > 4 || p.sk_out || p.kw_out || p.xs_w || p.persist_total < 0) { cs_set_error("conv_halo: bad grouped launch (%d phases)", p.nphase); return -1; }
+        // the phase's output offset is applied to out0 only: every other tensor of the epilogue would be read / written at the same addresses by all phases
+        if (p.res.p || p.out1.p || p.stat_out || p.pixscale || p.spmul || p.pool_hw) { cs_set_error("conv_halo: a grouped launch carries out0 only (no res / out1 / statistics / pixel scale / spmul / pooling)"); return -1; }
+        for (int z = 0; z < p.nphase; ++z)
+            if (p.ph_ooff[z] % 8u) { cs_set_error("conv_halo: output offset of phase %d (%u elements) is not a multiple of 8 (16-byte stores)", z, p.ph_ooff[z]); return -1; }
         grid.z = (unsigned)p.nphase;
     }
     if (p.sk_out) {

@@ -48,7 +48,9 @@ constexpr unsigned L_OOB = 0x80000000u;               // byte offset outside the
 typedef int l_i4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int l_u4_t __attribute__((ext_vector_type(4)));
 
-// one LDS-DMA instruction the compiler does not know of: 64 lanes x 16 bytes -> LDS at m0v + lane * 16
+// one LDS-DMA instruction the compiler does not know of: 64 lanes x 16 bytes -> LDS at m0v + lane * 16.  m0 cannot be
+// named as a clobber (hipcc: "reserved register, may not be preserved" - the clobber is ignored with a warning per expansion), so the guard is in
+// the build: _lib._isa_check_lat fails on any instruction of the kernel that names m0 outside this three-instruction sequence
 __device__ __forceinline__ void lat_dma16(unsigned m0v, unsigned voff, l_i4_t rsrc, int soff)
 {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -328,7 +330,7 @@ int lat_ep_code(const ConvParams& p)
 bool conv_lat_supported(const ConvParams& p, int mode)
 {
     if (p.KD != 1 || p.KH != 3 || p.KW != 3 || p.D != 1 || p.inD != 1 || p.up_shift || p.cg || p.hilo || p.ragged || p.sk_out || p.kw_out || p.xf_kind || p.spmul ||
-        p.pool_hw || p.xs_w) return false;
+        p.pool_hw || p.xs_w || p.nphase || p.PH != 1 || p.PW != 1) return false;
     if (p.Cin != 64 * L_NCK || p.H % 8 || p.W % 16) return false;
     if (mode == MODE_STD && p.stat_out) mode = MODE_STDSTAT;
     if (mode != MODE_STD && mode != MODE_STDSTAT && mode != MODE_TBLEND) return false;

@@ -942,7 +942,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
                 c.p.ph_wofs[n] = (long)(((intptr_t)Q.conv.w - (intptr_t)P.conv.w) / (intptr_t)sizeof(half_t));
                 c.p.ph_ooff[n] = (unsigned)(((long)Q.a * S + Q.b0) * 384);
                 c.p.ph_PH[n] = Q.ph; c.p.ph_PW[n] = Q.pw;
-                if (Q.conv.b != P.conv.b && Q.conv.macs_per_pos != P.conv.macs_per_pos) { cs_set_error("G.shared: phases of one group differ in more than weights / padding / offset"); return -1; }
+                if (Q.conv.macs_per_pos != P.conv.macs_per_pos || Q.conv.Cin != P.conv.Cin || Q.conv.KD != P.conv.KD || Q.conv.ragged != P.conv.ragged) { cs_set_error("G.shared: phases of one group differ in more than weights / padding / offset"); return -1; }
                 ++n;
             }
             c.p.nphase = n;
@@ -1300,6 +1300,20 @@ extern "C" int cs_finalize_weights(cs_engine* e)
                 b0 += nb;
             }
         }
+        // run_G launches phases of equal tap shape and width as ONE grouped launch that applies the first member's bias to all of them:
+        // hold the blobs to that here, once (pack.py replicates mlp_shared's bias per phase)
+        for (int i = 0; i < e->g_nshp[lv]; ++i)
+            for (int j = i + 1; j < e->g_nshp[lv]; ++j) {
+                const ConvL &A = e->g_shp[lv][i].conv, &Bc = e->g_shp[lv][j].conv;
+                if (A.KH != Bc.KH || A.KW != Bc.KW || A.Cout_pad != Bc.Cout_pad) continue;
+                std::vector<float> ha(A.Cout_pad), hb(A.Cout_pad);
+                CS_CHECK_HIP(hipMemcpy(ha.data(), A.b, ha.size() * sizeof(float), hipMemcpyDeviceToHost));
+                CS_CHECK_HIP(hipMemcpy(hb.data(), Bc.b, hb.size() * sizeof(float), hipMemcpyDeviceToHost));
+                if (memcmp(ha.data(), hb.data(), ha.size() * sizeof(float))) {
+                    cs_set_error("weights: '%s.b' and '%s.b' differ; phases of one grouped launch share one bias", A.name.c_str(), Bc.name.c_str());
+                    return -1;
+                }
+            }
     }
     auto get_gb = [&](const std::string& b, int C, cs_engine::GB* gb) -> int {
         const int pad = ((2 * C + 127) / 128) * 128;

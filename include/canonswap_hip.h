@@ -42,8 +42,10 @@ int cs_set_identity(cs_engine* e, int slot, const float* id, void* stream);
 /* Single-frame latency mode (BASELINE configs[1]): launches that cannot fill the 256 CUs at one or two frames per call take forms that
  * add an output element's products in another (fixed) order than the batched path - the 512-channel 3x3 convs split their K loop over twelve waves
  * of a workgroup (conv_lat.hip), the deep hourglass levels over workgroups (split-K), R's volume convs emit 2-row statistics blocks.  Deterministic,
- * the same tolerance against the reference (>= 50 dB), not bit-identical with the default mode - which is why it is opt-in and never chosen by batch
- * size: a frame's bits do not depend on the batch it is part of.  3.9 ms per 512x512 frame against 5.4 ms on one MI355X. */
+ * the same tolerance against the reference (>= 50 dB), not bit-identical with the default mode - which is why it is opt-in: the DEFAULT mode never
+ * picks a summation order by batch size, so there a frame's bits do not depend on the batch it is part of.  That guarantee does NOT hold inside
+ * latency mode: conv_lat and the split-K forms are taken per launch by its workgroup count (N x tiles <= 256), so a frame run at B = 2 in this mode
+ * may differ in its last bits from the same frame at B = 1 (both deterministic, both inside the tolerance). */
 int cs_set_latency_mode(cs_engine* e, int on);
 
 /* ---- stage calls; B frames per call, B <= max_batch --------------------------------------------------- */

@@ -146,3 +146,22 @@ def test_b64_frames_bit_equal_to_b32_and_b1(state_dicts, swapper, batch, out32):
     assert torch.equal(r["out_u8"].cpu()[:32], out32[1]) and torch.equal(r["out_u8"].cpu()[32:], out32[1])
     one = swapper.swap_frames(args["img"][31:32].cuda(), args["x_t"][31:32].cuda(), args["x_can"][31:32].cuda(), idv.cuda(), want_u8=True)
     assert torch.equal(one["out"].cpu()[0], r["out"].cpu()[63])
+
+
+def test_b84_last_frames_bit_equal_to_b1(state_dicts, swapper, batch, out32):
+    """cs_create accepts up to 84 frames per launch (the largest tensor, g_a256 = 84 x 256 x 256 x 384 fp16 elements, is then 1.3 samples
+    short of 2^31 elements - the engine addresses inside a tensor with 32-bit element offsets).  Frames 82 and 83 of an 84-frame call, whose
+    offsets are the ones close to 2^31, == the same frames of the 32-frame call, and frame 0 too (parity had been checked to B = 80)."""
+    from canonswap_amd.can_swap_e2e import can_swapper
+    args, idv = batch
+    sw = can_swapper(None, state_dicts=state_dicts, max_batch=84)
+    try:
+        idx = torch.arange(84) % 32
+        r = sw.swap_frames(args["img"][idx].cuda(), args["x_t"][idx].cuda(), args["x_can"][idx].cuda(), idv.cuda(), want_u8=True)
+        torch.cuda.synchronize()
+        o, o8 = r["out"].cpu(), r["out_u8"].cpu()
+    finally:
+        sw.engine.close()
+    for j in (0, 41, 82, 83):
+        assert torch.equal(o[j], out32[0][j % 32]), j
+        assert torch.equal(o8[j], out32[1][j % 32]), j

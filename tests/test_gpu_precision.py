@@ -20,8 +20,9 @@ def _weights(family, np_sds):
     return synth.rescale_feature_volume(np_sds, {"vol_x10": 10.0, "vol_x0.1": 0.1, "vol_x100": 100.0}[family])
 
 
+@pytest.mark.parametrize("latency", [False, True])
 @pytest.mark.parametrize("family", ["heavy_tail", "vol_x10", "vol_x0.1", "vol_x100"])
-def test_frame_psnr_other_weight_families(family, state_dicts_np):
+def test_frame_psnr_other_weight_families(family, latency, state_dicts_np):
     from canonswap_amd import synth
     from canonswap_amd.can_swap_e2e import can_swapper
     from oracle import canonswap_ref as O
@@ -31,7 +32,7 @@ def test_frame_psnr_other_weight_families(family, state_dicts_np):
     idv = torch.from_numpy(synth.make_identity(5))
     with torch.no_grad():
         ref = O.swap_frame(sds, *args, idv)
-    sw = can_swapper(None, state_dicts=sds, max_batch=1)
+    sw = can_swapper(None, state_dicts=sds, max_batch=1, latency_mode=latency)     # latency mode: every 512-channel K loop and R's statistics in another order
     try:
         out = sw.swap_frames(*(a.cuda() for a in args), idv.cuda())["out"].cpu()
         f_s = sw.extract_feature_3d(args[0].cuda()).cpu()
@@ -39,6 +40,6 @@ def test_frame_psnr_other_weight_families(family, state_dicts_np):
         sw.engine.close()
     rel = float((f_s - ref["f_s"]).norm() / ref["f_s"].norm())
     p = O.psnr(out, ref["out"])
-    print(f"{family}: PSNR {p:.2f} dB, f_s rel {rel:.2e}, |f_s| max {float(ref['f_s'].abs().max()):.3g}, f_ref max {float(ref['f_ref'].abs().max()):.3g}")
+    print(f"{family}{' (latency mode)' if latency else ''}: PSNR {p:.2f} dB, f_s rel {rel:.2e}, |f_s| max {float(ref['f_s'].abs().max()):.3g}, f_ref max {float(ref['f_ref'].abs().max()):.3g}")
     assert rel < 5e-3, (family, rel)
     assert p >= PSNR_GATE, (family, p)
