@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fixed-job", action="store_true", help="skip the fixed-size job reported next to the weak-scaling figure")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame-per-call measurement (BASELINE configs[1], latency mode) reported next to the headline")
+    ap.add_argument("--no-chain", action="store_true", help="skip the whole-device-side-frame measurement (crops -> M -> generator -> SoftErosion -> paste-back) "
+                                                             "and the v2i body reported next to the headline")
+    ap.add_argument("--chain-size", default="1080x1920", help="HxW of the original frames the chain pastes back into")
     ap.add_argument("--latency-mode", action="store_true",
                     help="BASELINE configs[1] (--batch 1): cross-workgroup split-K for the launches that cannot fill the chip")
     ap.add_argument("--identities", type=int, default=1,
@@ -149,7 +152,9 @@ def main():
                        f"canonswap_blobs_{socket.gethostname()}_{os.environ.get('MASTER_PORT', os.getpid())}.npz")
     packer = (rank == 0) if share_gpu else (local_rank == 0)
     if packer:
-        sds = synth.to_torch(synth.make_state_dicts(0))
+        # + the motion extractor M: the chain leg below drives the generator from M's key-points; the other modules' weights
+        # do not depend on its presence (one RNG stream per tensor name)
+        sds = synth.to_torch(synth.make_state_dicts(0, modules=synth.MODULES + ("motion_extractor",)))
         blobs = pack.build_blobs(sds)
         if world > 1:
             np.savez(shm, **blobs)
@@ -165,10 +170,11 @@ def main():
                      latency_mode=a.latency_mode)
     # BASELINE configs[1] in the same line: a second engine of one frame in latency mode (N = 1 default run only; 0.5 GB of workspace)
     single_on = (rank == 0 and world == 1 and not a.no_single_frame and not a.latency_mode and B > 1 and not a.streams and a.frames <= 0
-                 and not a.no_fixed_job and max(1, min(a.identities, 8)) == 1)
-    sw1 = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), packed_blobs=blobs, max_batch=1,
-                      latency_mode=True) if single_on else None
-    del blobs
+                 and max(1, min(a.identities, 8)) == 1)
+    chain_on = (rank == 0 and world == 1 and not a.no_chain and not a.latency_mode and not a.streams and a.frames <= 0
+                and max(1, min(a.identities, 8)) == 1)
+    if not single_on:
+        del blobs                                            # the one-frame engine is built AFTER the headline timing
     eng = sw.engine
 
     # one-time broadcast of the source identities (2 KB each); every rank derives T's modulated weights locally
@@ -303,7 +309,9 @@ def main():
     # ---- BASELINE configs[1]: one 512x512 frame per call, latency mode (cs_set_latency_mode: DESIGN 5.8), inputs resident, every call synchronous
     # with the next only through the stream (the caller hands over frame after frame); 10 untimed + 200 timed calls
     single, single_out = None, None
-    if sw1 is not None:
+    if single_on:
+        sw1 = can_swapper(type("Cfg", (), {"device_id": local_rank, "flag_force_cpu": False})(), packed_blobs=blobs, max_batch=1, latency_mode=True)
+        del blobs
         e1 = sw1.engine
         e1.set_identity(sid[0:1], slot=0)
         o1 = torch.empty(1, 512, 512, 3, dtype=torch.uint8, device=dev)
@@ -327,6 +335,116 @@ def main():
                   "frames": n1, "ms_per_frame": round(d1 / n1 * 1e3, 3), "value": round(n1 / d1, 3), "unit": "frames/s",
                   "conv_roofline_frac_end_to_end": round(ALGO_GFLOP_PER_FRAME * 1e9 * (n1 / d1) / (PEAK_TFLOPS_F16 * 1e12), 4)}
         e1.close()
+
+
+    # ---- the whole device-side frame (SURVEY 8f rows N1-N3 around the generator): uint8 512x512 crops resident in HBM ->
+    # cs_prepare_crops -> cs_motion_extract + cs_motion_keypoints -> cs_swap_frames_ids -> cs_soft_erosion_frames -> cs_paste_back_batch -> uint8
+    # frames of the original size, B frames per launch; next to it the generator alone on the SAME key-points, and the v2i body (row N4)
+    chain, animate = None, None
+    if chain_on:
+        import csv as _csv
+        import tempfile
+        from canonswap_amd.chain import FrameChain
+        Ho, Wo = (int(v) for v in a.chain_size.lower().split("x"))
+        fc = FrameChain(sw)
+        smooth = synth.make_smooth_images(B, seed=2100, size=512)                        # crops M can tell apart (white noise pools to one feature)
+        crops = torch.from_numpy(np.ascontiguousarray((smooth.transpose(0, 2, 3, 1) * 255).astype(np.uint8))).to(dev)
+        del smooth
+        yy, xx = np.mgrid[0:512, 0:512].astype(np.float32)
+        rr = np.random.Generator(np.random.PCG64(77))
+        mk = np.stack([(((xx - rr.uniform(216, 296)) / rr.uniform(120, 190)) ** 2 + ((yy - rr.uniform(216, 296)) / rr.uniform(150, 215)) ** 2 <= 1)
+                       for _ in range(B)]).astype(np.uint8)                              # face-parsing labels: one 0/1 ellipse per frame
+        masks = torch.from_numpy(mk).to(dev)
+        ori = torch.randint(0, 256, (B, Ho, Wo, 3), dtype=torch.uint8, device=dev)
+        outf = torch.empty_like(ori)
+        Ms = np.zeros((B, 2, 3))
+        for j in range(B):                                                               # crop -> frame: a face 0.35-0.5 of the frame height
+            sc, th = rr.uniform(0.35, 0.5) * Ho / 512.0, rr.uniform(-0.2, 0.2)
+            Ms[j] = [[sc * np.cos(th), -sc * np.sin(th), rr.uniform(0.25, 0.45) * Wo], [sc * np.sin(th), sc * np.cos(th), rr.uniform(0.1, 0.3) * Ho]]
+        slots0 = [0] * B
+
+        def chain_step():
+            return fc(crops, masks, Ms, ori, slots=slots0, out=outf, keep=True)
+        for _ in range(2):
+            r0 = chain_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            chain_step()
+        torch.cuda.synchronize(dev)
+        cdt = time.perf_counter() - t0
+        I_c, xt_c, xc_c = r0["I"], r0["x_t"].clone(), r0["x_can"].clone()
+        gen_u8 = torch.empty(B, 512, 512, 3, dtype=torch.uint8, device=dev)
+
+        def gen_step():
+            eng.swap_frames(I_c, xt_c, xc_c, None, want_f32=False, want_u8=True, out_u8=gen_u8, slots=slots0)
+        for _ in range(2):
+            gen_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            gen_step()
+        torch.cuda.synchronize(dev)
+        gdt = time.perf_counter() - t0
+        # per-stage device time of one chain step: HIP events around every launch, summed by stage
+        tmp = tempfile.NamedTemporaryFile(suffix=".csv", delete=False); tmp.close()
+        old_csv = os.environ.get("CANONSWAP_PROFILE_CSV")
+        os.environ["CANONSWAP_PROFILE_CSV"] = tmp.name
+        eng.profile_begin()
+        chain_step()
+        eng.profile_end()
+        if old_csv is None:
+            del os.environ["CANONSWAP_PROFILE_CSV"]
+        else:
+            os.environ["CANONSWAP_PROFILE_CSV"] = old_csv
+        stage_ms = {"prepare_crops": 0.0, "motion_extractor": 0.0, "m_keypoints": 0.0, "generator": 0.0, "soft_erosion": 0.0, "paste_back": 0.0}
+        with open(tmp.name) as f:
+            for row in _csv.DictReader(f):
+                lab, ms = row["label"], float(row["ms"])
+                key = ("prepare_crops" if lab == "prepare_crops" else "m_keypoints" if lab == "m_keypoints" else
+                       "motion_extractor" if (lab.startswith("M.") or lab.startswith("m_")) else "soft_erosion" if lab == "soft_erosion" else
+                       "paste_back" if lab == "paste_back_batch" else "generator")
+                stage_ms[key] += ms
+        os.remove(tmp.name)
+        px = Ho * Wo
+        stage_bytes = {"prepare_crops": 2 * 786432.0, "soft_erosion": 262144.0 + 4 * 262144.0, "paste_back": 2.0 * px * 3 + 786432 + 4 * 262144}
+        chain = {"workload": f"whole device-side frame, {B} frames per launch: uint8 512x512 crops in HBM -> INTER_AREA 256x256 + /255 -> motion extractor M "
+                             f"+ transform_keypoint -> F->W->T->R->W->G -> SoftErosion(21, 0.9, 3) of the 0/1 face mask -> warpAffine paste-back into {Ho}x{Wo} "
+                             "uint8 frames (can_swap_pipeline_e2e.py:111-125, 196, 242-283 without its host round trips)",
+                 "frames": K * B, "value": round(K * B / cdt, 3), "unit": "frames/s", "ms_per_step": round(cdt / K * 1e3, 3),
+                 "generator_alone_same_keypoints": round(K * B / gdt, 3), "ratio_to_generator": round(gdt / cdt, 4),
+                 "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
+                 "stage_rates": {"prepare_crops_GBps": round(stage_bytes["prepare_crops"] * B / max(stage_ms["prepare_crops"], 1e-9) / 1e6, 1),
+                                 "soft_erosion_GBps": round(stage_bytes["soft_erosion"] * B / max(stage_ms["soft_erosion"], 1e-9) / 1e6, 1),
+                                 "soft_erosion_fp32_TFLOPs": round(2 * 441 * 262144 * 3 * B / max(stage_ms["soft_erosion"], 1e-9) / 1e9, 2),
+                                 "paste_back_GBps": round(stage_bytes["paste_back"] * B / max(stage_ms["paste_back"], 1e-9) / 1e6, 1),
+                                 "motion_extractor_algorithmic_TFLOPs": round(11.6 * B / max(stage_ms["motion_extractor"], 1e-9), 1)},
+                 "stage_rates_basis": "algorithmic bytes per frame: prepare_crops 786 KB in + 786 KB out; soft_erosion 262 KB of labels in + 1 MB soft mask out, "
+                                      "0.69 GFLOP of fp32 FMAs (three 21x21 cone convolutions, crop.py:29-41); paste_back original frame in + out, crop and "
+                                      "mask in; M 11.6 GFLOP (SURVEY 8f), run in split precision (three fp16 MFMA passes)"}
+        del ori, outf, crops, masks, fc
+        # ---- v2i body (row N4; can_swap_pipeline_v2i.py:311-312): warp_decode of ONE swapped canonical volume under B driving key-point sets
+        with torch.no_grad():
+            f_can = eng.extract_feature_3d(pool["img"][0:1])
+        xs = pool["x_can"][0:1].contiguous()
+        kd = pool["x_t"][:B].contiguous()
+
+        def v2i_step():
+            eng.animate_frames(f_can, xs, kd, want_f32=False, want_u8=True, out_u8=gen_u8)
+        for _ in range(2):
+            v2i_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            v2i_step()
+        torch.cuda.synchronize(dev)
+        vdt = time.perf_counter() - t0
+        V2I_GFLOP = 342.07 + 891.57                        # W.forward + G per frame
+        animate = {"workload": f"v2i per-frame body (can_swap_pipeline_v2i.py:311-312): warp_decode of one swapped canonical volume under {B} driving "
+                               "key-point sets per launch (cs_animate_frames, shared volume)",
+                   "frames": K * B, "value": round(K * B / vdt, 3), "unit": "frames/s", "ms_per_step": round(vdt / K * 1e3, 3),
+                   "conv_roofline_frac_end_to_end": round(V2I_GFLOP * 1e9 * (K * B / vdt) / (PEAK_TFLOPS_F16 * 1e12), 4)}
+        del gen_u8
 
     # ---- roofline of the dominant kernel family (conv_halo_kernel): HIP events around every launch, same workload
     prof = None
@@ -459,6 +577,10 @@ def main():
             line["fixed_job"] = fixed
         if single:
             line["single_frame"] = single
+        if chain:
+            line["chain"] = chain
+        if animate:
+            line["v2i_body"] = animate
         if a.streams:
             per = []
             for s, g in enumerate(groups):

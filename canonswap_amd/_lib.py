@@ -24,10 +24,10 @@ ABI_SYMBOLS = [
     "cs_create", "cs_destroy", "cs_last_error", "cs_abi_version", "cs_upload", "cs_finalize_weights", "cs_set_identity", "cs_set_latency_mode",
     "cs_extract_feature_3d", "cs_warp", "cs_warp_out", "cs_swap", "cs_swap_ids", "cs_swap_frames_ids", "cs_refine", "cs_warp_forward", "cs_spade_decode",
     "cs_pack_u8", "cs_unpack_u8", "cs_soft_erosion", "cs_prepare_crops", "cs_warp_affine_u8", "cs_warp_affine_f32", "cs_paste_back",
-    "cs_motion_extract", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
+    "cs_motion_extract", "cs_motion_keypoints", "cs_soft_erosion_frames", "cs_paste_back_batch", "cs_swap_frames", "cs_animate_frames", "cs_profile_begin", "cs_profile_end", "cs_profile_exec_flops", "cs_op_conv", "cs_op_grid_sample3d",
     "cs_op_chan_stats", "cs_op_chan_stats_partial_floats", "cs_op_pair_ragged", "cs_op_resblock3d", "cs_op_t_mask",
 ]
-ABI_VERSION = 3          # CS_ABI_VERSION of include/canonswap_hip.h
+ABI_VERSION = 4          # CS_ABI_VERSION of include/canonswap_hip.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -389,6 +389,9 @@ def load():
     lib.cs_warp_affine_u8.argtypes = [vp, vp, ci, ci, d6, vp, ci, ci, vp]
     lib.cs_warp_affine_f32.argtypes = [vp, vp, ci, ci, d6, vp, ci, ci, vp]
     lib.cs_paste_back.argtypes = [vp, vp, vp, vp, ci, ci, d6, vp, vp, ci, ci, vp]
+    lib.cs_soft_erosion_frames.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, cf, ci, vp, vp, vp]
+    lib.cs_paste_back_batch.argtypes = [vp, ci, vp, vp, ci, ci, C.POINTER(C.c_double), vp, vp, ci, ci, vp]
+    lib.cs_motion_keypoints.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     lib.cs_animate_frames.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp]
     lib.cs_swap_frames.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.cs_profile_begin.argtypes = [vp]

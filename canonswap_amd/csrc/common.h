@@ -237,14 +237,17 @@ int launch_lrelu16(const half_t* in, half_t* out, long n, float slope, hipStream
 int launch_unpack_u8(const uint8_t* in, float* out, int N, int C, int H, int W, hipStream_t st);
 
 // ---- image-space steps around the generator (imgops.hip)
-int launch_soft_erosion(const float* mask, float* tmp_a, float* tmp_b, const float* w, float* part, float* soft, unsigned char* hard,
-                        int B, int H, int W, int ksize, float thr, int iters, hipStream_t st);
+int launch_soft_erosion(const void* mask, int mask_u8, float* tmp_a, float* tmp_b, const float* w, float* part, float* soft, unsigned char* hard,
+                        int B, int H, int W, int ksize, float thr, int iters, int per_sample, hipStream_t st);
+int launch_paste_batch(const unsigned char* crops, const float* masks, int Hc, int Wc, const double* M, const unsigned char* oris,
+                       unsigned char* outs, int B, int Ho, int Wo, hipStream_t st);
 int launch_prepare_crops(const unsigned char* in, float* out, int B, int Hc, int Wc, int factor, hipStream_t st);
 int launch_paste(const unsigned char* crop, const float* mask_crop, const float* mask_ori, int Hc, int Wc, const double M[6],
                  const unsigned char* ori, unsigned char* out, int Ho, int Wo, hipStream_t st);
 int launch_warp_f32(const float* src, int Hs, int Ws, const double M[6], float* dst, int Hd, int Wd, hipStream_t st);
 
 // ---- motion extractor pieces (motion.hip)
+int launch_m_keypoints(const float* raw, float* x_t, float* x_can, float* rot, int N, hipStream_t st);
 int launch_m_stem(const float* img, const float* w, const float* b, const float* g, const float* be, float* x, int N, int HI, int WI, hipStream_t st);
 int launch_m_dwln(const float* x, const float* wt, const float* b, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st);
 int launch_m_ln_s2d(const float* x, const float* g, const float* be, half_t* y, int N, int H, int W, int C, hipStream_t st);

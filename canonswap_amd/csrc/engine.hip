@@ -22,6 +22,7 @@ void cs_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* cs_last_error(void) { return g_err; }
+// 4 (round 6): cs_soft_erosion_frames, cs_paste_back_batch, cs_motion_keypoints.
 // 3 (round 4): cs_conv_desc grew (hilo, stat_out, xf_*, ep_general), cs_op_conv takes conv_halo / vol32 / conv_wide configurations only, the
 // packed weight blobs of F.down0 / down1 / second carry [W_hi | W_lo], W.occ49 exists; cs_conv_desc::pool_hw.  _lib.load() refuses any other value.
 extern "C" int cs_abi_version(void) { return CS_ABI_VERSION; }
@@ -732,17 +733,12 @@ int run_T(cs_engine* e, int B, const int* slots, int* cur, hipStream_t st)
 
 // ------------------------------------------------------------------------------------------------ R
 // G3d.forward (adaptive_modulate.py:721-733). x: fp32 vs[*cur] + fp16 va[0]; result fp32 in vs[*cur].
-// Split precision (default on; CANONSWAP_R_SPLIT=0 is the A/B knob): the two convs of a stage-3 block feed GroupNorms, which divide
+// Split precision: the two convs of a stage-3 block feed GroupNorms, which divide
 // by the std of the conv output - the fp16 rounding of operands there costs 1.5e-3 relative error on the refined volume (every
 // other stage: 1-4e-4) and sets the PSNR of the whole frame (50-57 dB depending on the frame).  With activations [hi | lo] and
 // weights [W_hi | W_lo | W_hi] (three 32-channel weight chunks, the hi halo staged once: ConvParams::hilo) the same fp16 MFMA kernel
-// computes W_hi x_hi + W_lo x_hi + W_hi x_lo, good to about 2^-21.
-bool r_split()
-{
-    static const bool on = [] { const char* s = getenv("CANONSWAP_R_SPLIT"); return s ? atoi(s) != 0 : true; }();
-    return on;
-}
-
+// computes W_hi x_hi + W_lo x_hi + W_hi x_lo, good to about 2^-21.  There is no switch: the plain fp16 form measured 49.5 dB on the worst
+// pool frame, below the 50 dB gate (round 6: the CANONSWAP_R_SPLIT knob is gone).
 TDesc hwdc3_split(void* p) { return td(p, VOL * 2, 64, (long)FW * FD * 64, (long)FD * 64); }
 
 // Stage-3 blocks with the GroupNorm apply fused into the consumer convolution (vol32 transform staging, ConvParams::xf_*): per block
@@ -794,27 +790,26 @@ int run_stage3_xf(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affin
 
 int run_stage3(cs_engine* e, cs_engine::S3* blk, int B, int* cur, const Affine* last_pre, hipStream_t st)
 {
-    const bool sp = r_split();
-    if (sp && vol32_xf()) return run_stage3_xf(e, blk, B, cur, last_pre, st);
-    if (sp) TRY(e->run(1, st, [&] { return launch_split16(e->vs[*cur], e->vsp[0], (long)B * VOL, st); }, "split16"));
+    if (vol32_xf()) return run_stage3_xf(e, blk, B, cur, last_pre, st);
+    TRY(e->run(1, st, [&] { return launch_split16(e->vs[*cur], e->vsp[0], (long)B * VOL, st); }, "split16"));
     for (int i = 0; i < 3; ++i) {   // ResBlock3D_stage3_leak (util.py:528-544)
         const int y = (*cur + 1) % 3, nxt = (*cur + 2) % 3;
-        ConvCall c1 = sp ? mk(blk[i].c1sp, e->vsp[0], hwdc3_split(nullptr), B, FD, FH, FW) : mk(blk[i].c1, e->va[0], hwdc3(nullptr), B, FD, FH, FW);
-        c1.p.hilo = sp;
+        ConvCall c1 = mk(blk[i].c1sp, e->vsp[0], hwdc3_split(nullptr), B, FD, FH, FW);
+        c1.p.hilo = 1;
         c1.p.out0 = hwdc3(e->vs[y]); c1.p.out0_f32 = 1;
         c1.hcfg = cfg_v32();
         float* s1;
         TRY(go_stats(e, c1, 32, VOX, &s1, st, 4, 4));
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s1, blk[i].g1, blk[i].b1, nullptr, 0.01f, nullptr,
-                                                       sp ? e->vsp[1] : e->va[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st, sp); }, "norm_act"));
-        ConvCall c2 = sp ? mk(blk[i].c2sp, e->vsp[1], hwdc3_split(nullptr), B, FD, FH, FW) : mk(blk[i].c2, e->va[1], hwdc3(nullptr), B, FD, FH, FW);
-        c2.p.hilo = sp;
+                                                       e->vsp[1], nullptr, nullptr, 32, ACT_NONE, 0.f, B, VOL, st, 1); }, "norm_act"));
+        ConvCall c2 = mk(blk[i].c2sp, e->vsp[1], hwdc3_split(nullptr), B, FD, FH, FW);
+        c2.p.hilo = 1;
         c2.p.out0 = hwdc3(e->vs[y]); c2.p.out0_f32 = 1;
         c2.hcfg = cfg_v32();
         float* s2;
         TRY(go_stats(e, c2, 32, VOX, &s2, st, 4, 4));
         const bool pre = (i == 2 && last_pre);
-        const bool sp_out = sp && i < 2;            // the next stage-3 block reads split precision; everything else plain fp16
+        const bool sp_out = i < 2;                  // the next stage-3 block reads split precision; everything else plain fp16
         TRY(e->run(1, st, [&] { return launch_norm_act(e->vs[y], s2, blk[i].g2, blk[i].b2, e->vs[*cur], 0.01f,
                                                        e->vs[nxt], sp_out ? e->vsp[0] : e->va[0], pre ? last_pre->s : nullptr,
                                                        pre ? last_pre->t : nullptr, 512, pre ? ACT_LRELU : ACT_NONE, 0.01f, B, VOL, st, sp_out); },
@@ -1542,10 +1537,11 @@ extern "C" int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, co
 }
 
 // ---- image-space steps around the generator
-extern "C" int cs_soft_erosion(cs_engine* e, int B, int H, int W, const float* mask, const float* w, int ksize, float thr, int iters,
-                               float* soft_out, uint8_t* hard_out, void* stream)
+static int soft_erosion_impl(cs_engine* e, int B, int H, int W, const void* mask, int mask_u8, const float* w, int ksize, float thr, int iters,
+                             float* soft_out, uint8_t* hard_out, int per_sample, void* stream, const char* who)
 {
-    if (!e || !mask || !w || !soft_out || B < 1 || H < 1 || W < 1) { cs_set_error("cs_soft_erosion: bad arguments"); return -1; }
+    if (!e || !mask || !w || !soft_out || B < 1 || H < 1 || W < 1) { cs_set_error("%s: bad arguments", who); return -1; }
+    if (B > 64) { cs_set_error("%s: batch %d exceeds 64", who, B); return -1; }
     DevGuard guard(e->dev);
     const size_t need = (size_t)B * H * W;
     if (need > e->se_cap) {      // grow-only scratch; buffers of earlier sizes stay owned by the engine until cs_destroy
@@ -1553,10 +1549,21 @@ extern "C" int cs_soft_erosion(cs_engine* e, int B, int H, int W, const float* m
         if (!e->se_part && e->alloc(&e->se_part, (size_t)64 * 64)) return -1;
         e->se_cap = need;
     }
-    if (B > 64) { cs_set_error("cs_soft_erosion: batch %d exceeds 64", B); return -1; }
     hipStream_t st = (hipStream_t)stream;
-    return e->run(1, st, [&] { return launch_soft_erosion(mask, e->se_a, e->se_b, w, e->se_part, soft_out, hard_out, B, H, W, ksize, thr, iters, st); },
-                  "soft_erosion");
+    return e->run(1, st, [&] { return launch_soft_erosion(mask, mask_u8, e->se_a, e->se_b, w, e->se_part, soft_out, hard_out, B, H, W, ksize, thr, iters,
+                                                          per_sample, st); }, "soft_erosion");
+}
+
+extern "C" int cs_soft_erosion(cs_engine* e, int B, int H, int W, const float* mask, const float* w, int ksize, float thr, int iters,
+                               float* soft_out, uint8_t* hard_out, void* stream)
+{
+    return soft_erosion_impl(e, B, H, W, mask, 0, w, ksize, thr, iters, soft_out, hard_out, 0, stream, "cs_soft_erosion");
+}
+
+extern "C" int cs_soft_erosion_frames(cs_engine* e, int B, int H, int W, const void* masks, int masks_u8, const float* w, int ksize, float thr,
+                                      int iters, float* soft_out, uint8_t* hard_out, void* stream)
+{
+    return soft_erosion_impl(e, B, H, W, masks, masks_u8 != 0, w, ksize, thr, iters, soft_out, hard_out, 1, stream, "cs_soft_erosion_frames");
 }
 
 extern "C" int cs_prepare_crops(cs_engine* e, int B, const uint8_t* crops, int Hc, int Wc, float* out, void* stream)
@@ -1595,6 +1602,26 @@ extern "C" int cs_paste_back(cs_engine* e, const uint8_t* crop, const float* mas
     DevGuard guard(e->dev);
     hipStream_t st = (hipStream_t)stream;
     return e->run(1, st, [&] { return launch_paste(crop, mask_crop, mask_ori, Hc, Wc, M_c2o, img_ori, out, Ho, Wo, st); }, "paste_back");
+}
+
+extern "C" int cs_paste_back_batch(cs_engine* e, int B, const uint8_t* crops, const float* masks_crop, int Hc, int Wc, const double* M_c2o,
+                                   const uint8_t* imgs_ori, uint8_t* out, int Ho, int Wo, void* stream)
+{
+    if (!e || !crops || !masks_crop || !M_c2o || !imgs_ori || !out || B < 1 || Hc < 1 || Wc < 1 || Ho < 1 || Wo < 1) {
+        cs_set_error("cs_paste_back_batch: bad arguments");
+        return -1;
+    }
+    DevGuard guard(e->dev);
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_paste_batch(crops, masks_crop, Hc, Wc, M_c2o, imgs_ori, out, B, Ho, Wo, st); }, "paste_back_batch");
+}
+
+extern "C" int cs_motion_keypoints(cs_engine* e, int B, const float* raw, float* x_t, float* x_can, float* rot, void* stream)
+{
+    if (!e || !raw || !x_t || !x_can || B < 1) { cs_set_error("cs_motion_keypoints: bad arguments"); return -1; }
+    DevGuard guard(e->dev);
+    hipStream_t st = (hipStream_t)stream;
+    return e->run(1, st, [&] { return launch_m_keypoints(raw, x_t, x_can, rot, B, st); }, "m_keypoints");
 }
 
 extern "C" int cs_profile_begin(cs_engine* e)

@@ -20,31 +20,60 @@
 
 // ---------------------------------------------------------------------------------------------- SoftErosion
 // one pass: out = conv2d(in, w, padding = r) [zero padding], optionally out = min(in, out)  (crop.py:38-41)
-template <int KS>
-__global__ void __launch_bounds__(256) se_conv_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+// Round 6: register tiled.  A workgroup owns 64 x 32 outputs, a thread 8 consecutive outputs of one row: per kernel row it reads the
+// 8 + KS - 1 inputs it needs ONCE from LDS (seven ds_read_b128; the lane -> address map (row stride 84 floats, 32 B between lanes) is
+// conflict free for that instruction: the 16 lanes of a group cover the 64 banks) and issues KS x 8 FMAs on them, the weights are
+// wave-uniform scalar loads.  One LDS read per six FMAs instead of two per FMA: the pass is VALU-bound (0.69 GFLOP per frame and
+// three passes, crop.py:29-35 - the kernel is a cone, not separable).  An output's products are added in the order (ky, kx) ascending.
+// IN: float (0/1 masks as the reference's .float() makes them, or the previous pass) or uint8 (0/1 labels straight from the parser).
+template <int KS, typename IN>
+__global__ void __launch_bounds__(256) se_conv_kernel(const IN* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
                                                       int H, int W, int take_min)
 {
-    constexpr int R = KS / 2, TW = 32, TH = 8, LW = TW + 2 * R, LH = TH + 2 * R;
-    __shared__ float tile[LH][LW + 1];
-    __shared__ float wk[KS * KS];
+    constexpr int R = KS / 2, NX = 8, TW = 64, TH = 32, LW = 84, LH = TH + 2 * R, NV = (NX + 2 * R + 3) / 4;
+    static_assert(TW + 2 * R <= LW && LW % 8 == 4, "row stride: 16 B aligned and an odd multiple of 16 B");
+    __shared__ __attribute__((aligned(16))) float tile[LH * LW + 4];
     const int n = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const float* src = in + (long)n * H * W;
-    for (int i = threadIdx.x; i < KS * KS; i += 256) wk[i] = w[i];
+    const IN* src = in + (long)n * H * W;
     for (int i = threadIdx.x; i < LH * LW; i += 256) {
         const int ly = i / LW, lx = i % LW, y = y0 + ly - R, x = x0 + lx - R;
-        tile[ly][lx] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? src[(long)y * W + x] : 0.f;
+        tile[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (float)src[(long)y * W + x] : 0.f;
     }
     __syncthreads();
-    const int tx = threadIdx.x % TW, ty = threadIdx.x / TW;
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= W || y >= H) return;
-    float acc = 0.f;
-#pragma unroll 1
-    for (int ky = 0; ky < KS; ++ky)
+    const int g = threadIdx.x & 7, r = threadIdx.x >> 3;
+    float acc[NX];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) acc = fmaf(tile[ty + ky][tx + kx], wk[ky * KS + kx], acc);
-    const float c = tile[ty + R][tx + R];
-    out[(long)n * H * W + (long)y * W + x] = take_min ? fminf(c, acc) : acc;
+    for (int o = 0; o < NX; ++o) acc[o] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < KS; ++ky) {
+        const float4* rp = (const float4*)(tile + (r + ky) * LW + g * NX);
+        float v[NV * 4];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { const float4 q = rp[j]; v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w; }
+        const float* wr = w + ky * KS;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const float wv = wr[kx];
+#pragma unroll
+            for (int o = 0; o < NX; ++o) acc[o] = fmaf(v[o + kx], wv, acc[o]);
+        }
+    }
+    const int y = y0 + r, xb = x0 + g * NX;
+    if (y >= H) return;
+    float res[NX];
+#pragma unroll
+    for (int o = 0; o < NX; ++o) {
+        const float c = tile[(r + R) * LW + g * NX + R + o];
+        res[o] = take_min ? fminf(c, acc[o]) : acc[o];
+    }
+    float* dst = out + (long)n * H * W + (long)y * W + xb;
+    if (xb + NX <= W && (W & 3) == 0) {
+        ((float4*)dst)[0] = make_float4(res[0], res[1], res[2], res[3]);
+        ((float4*)dst)[1] = make_float4(res[4], res[5], res[6], res[7]);
+    } else {
+#pragma unroll
+        for (int o = 0; o < NX; ++o) if (xb + o < W) dst[o] = res[o];
+    }
 }
 
 // max over the pixels below the threshold (crop.py:45: `x[~mask].max()` runs over the WHOLE (N,1,H,W) tensor, not per sample -
@@ -66,9 +95,10 @@ __global__ void __launch_bounds__(256) se_max_kernel(const float* __restrict__ x
 }
 
 __global__ void __launch_bounds__(256) se_final_kernel(float* __restrict__ x, long P, float thr, const float* __restrict__ part, int nparts,
-                                                       unsigned char* __restrict__ hard)
+                                                       unsigned char* __restrict__ hard, int per_sample)
 {
     const int n = blockIdx.y;
+    if (per_sample) part += (long)n * nparts;      // B independent calls of the module (the pipeline's loop): the maximum of this sample only
     // nparts = blocks x samples: the maximum over the whole batch.  One cooperative pass per workgroup (threads stride over the partials,
     // wave butterfly, four wave results through LDS) instead of every thread looping over all of them (4096 broadcast loads per thread at
     // 64 frames: ADVICE r3); max is order independent, so the value is the same.
@@ -87,18 +117,25 @@ __global__ void __launch_bounds__(256) se_final_kernel(float* __restrict__ x, lo
     if (hard) hard[(long)n * P + i] = hi ? 1 : 0;
 }
 
-int launch_soft_erosion(const float* mask, float* tmp_a, float* tmp_b, const float* w, float* part, float* soft, unsigned char* hard,
-                        int B, int H, int W, int ksize, float thr, int iters, hipStream_t st)
+int launch_soft_erosion(const void* mask, int mask_u8, float* tmp_a, float* tmp_b, const float* w, float* part, float* soft, unsigned char* hard,
+                        int B, int H, int W, int ksize, float thr, int iters, int per_sample, hipStream_t st)
 {
     if (ksize != 21 && ksize != 15) { cs_set_error("soft_erosion: kernel size %d (21 and 15 are built)", ksize); return -1; }
     if (iters < 1) { cs_set_error("soft_erosion: iterations %d", iters); return -1; }
-    const dim3 grid((W + 31) / 32, (H + 7) / 8, B);
-    const float* src = mask;
+    const dim3 grid((W + 63) / 64, (H + 31) / 32, B);
+    const float* src = nullptr;
     for (int it = 0; it < iters; ++it) {
         const bool last = it == iters - 1;
         float* dst = last ? soft : (it % 2 == 0 ? tmp_a : tmp_b);
-        if (ksize == 21) hipLaunchKernelGGL(se_conv_kernel<21>, grid, dim3(256), 0, st, src, w, dst, H, W, last ? 0 : 1);
-        else hipLaunchKernelGGL(se_conv_kernel<15>, grid, dim3(256), 0, st, src, w, dst, H, W, last ? 0 : 1);
+        const int tm = last ? 0 : 1;
+        if (it == 0 && mask_u8) {
+            if (ksize == 21) hipLaunchKernelGGL((se_conv_kernel<21, unsigned char>), grid, dim3(256), 0, st, (const unsigned char*)mask, w, dst, H, W, tm);
+            else hipLaunchKernelGGL((se_conv_kernel<15, unsigned char>), grid, dim3(256), 0, st, (const unsigned char*)mask, w, dst, H, W, tm);
+        } else {
+            const float* s_ = it == 0 ? (const float*)mask : src;
+            if (ksize == 21) hipLaunchKernelGGL((se_conv_kernel<21, float>), grid, dim3(256), 0, st, s_, w, dst, H, W, tm);
+            else hipLaunchKernelGGL((se_conv_kernel<15, float>), grid, dim3(256), 0, st, s_, w, dst, H, W, tm);
+        }
         LAUNCH_CHECK("se_conv");
         src = dst;
     }
@@ -106,7 +143,8 @@ int launch_soft_erosion(const float* mask, float* tmp_a, float* tmp_b, const flo
     const int nparts = 64;
     hipLaunchKernelGGL(se_max_kernel, dim3(nparts, B), dim3(256), 0, st, soft, P, thr, part);
     LAUNCH_CHECK("se_max");
-    hipLaunchKernelGGL(se_final_kernel, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, st, soft, P, thr, part, nparts * B, hard);
+    hipLaunchKernelGGL(se_final_kernel, dim3((unsigned)((P + 255) / 256), B), dim3(256), 0, st, soft, P, thr, part, per_sample ? nparts : nparts * B, hard,
+                       per_sample);
     LAUNCH_CHECK("se_final");
     return 0;
 }
@@ -202,6 +240,58 @@ __global__ void __launch_bounds__(256) paste_kernel(const unsigned char* __restr
     }
 }
 
+// ---- the paste-back step of B frames in one launch (can_swap_pipeline_e2e.py:273-283 per frame: SoftErosion mask -> prepare_paste_back ->
+// paste_back).  blockIdx.y = frame; a thread owns four consecutive pixels of a row = 12 bytes = three dwords of the original and of the
+// result (the single-frame kernel above moves them byte by byte).  A pixel whose source position lies outside the crop has mask 0 and
+// warped value 0: v = 0 * 0 + (1 - 0) * ori = ori exactly, so it is copied - most of a 1080p frame.  Same arithmetic per pixel as
+// paste_kernel with mask_crop (tests/test_gpu_chain.py holds the two bit-equal).
+struct AffineBatch { AffineInv a[64]; };      // 3 KB of kernel arguments: no device-side staging buffer, nothing to race with
+
+__global__ void __launch_bounds__(256) paste_batch_kernel(const unsigned char* __restrict__ crops, const float* __restrict__ masks, int Hc, int Wc,
+                                                          AffineBatch AB, const unsigned char* __restrict__ oris,
+                                                          unsigned char* __restrict__ outs, int Ho, int Wo)
+{
+    const int n = blockIdx.y;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;          // group of four pixels
+    const long P = (long)Ho * Wo;
+    if (q * 4 >= P) return;
+    const AffineInv& A = AB.a[n];
+    const unsigned char* crop = crops + (long)n * Hc * Wc * 3;
+    const float* mask_crop = masks + (long)n * Hc * Wc;
+    const unsigned* ori = (const unsigned*)(oris + (long)n * P * 3) + q * 3;
+    unsigned* out = (unsigned*)(outs + (long)n * P * 3) + q * 3;
+    unsigned wv[3] = {ori[0], ori[1], ori[2]};
+    unsigned char* px = (unsigned char*)wv;
+    const int y = (int)((q * 4) / Wo), xb = (int)((q * 4) % Wo);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int sx, sy, fx, fy;
+        affine_coords(A, xb + k, y, sx, sy, fx, fy);
+        if (sx < -1 || sy < -1 || sx >= Wc || sy >= Hc) continue;          // all four taps outside: the original pixel
+        const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+        const bool y0 = (unsigned)sy < (unsigned)Hc, y1 = (unsigned)(sy + 1) < (unsigned)Hc;
+        const bool x0 = (unsigned)sx < (unsigned)Wc, x1 = (unsigned)(sx + 1) < (unsigned)Wc;
+        const long o00 = (long)sy * Wc + sx;
+        const float ax = (float)fx * 0.03125f, ay = (float)fy * 0.03125f;
+        const float f00 = (1.f - ay) * (1.f - ax), f01 = (1.f - ay) * ax;
+        const float f10 = ay * (1.f - ax), f11 = ay * ax;
+        const float m00 = (y0 && x0) ? mask_crop[o00] : 0.f, m01 = (y0 && x1) ? mask_crop[o00 + 1] : 0.f;
+        const float m10 = (y1 && x0) ? mask_crop[o00 + Wc] : 0.f, m11 = (y1 && x1) ? mask_crop[o00 + Wc + 1] : 0.f;
+        const float m = ((m00 * f00 + m01 * f01) + m10 * f10) + m11 * f11;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int t00 = (y0 && x0) ? crop[o00 * 3 + c] : 0;
+            const int t01 = (y0 && x1) ? crop[(o00 + 1) * 3 + c] : 0;
+            const int t10 = (y1 && x0) ? crop[(o00 + Wc) * 3 + c] : 0;
+            const int t11 = (y1 && x1) ? crop[(o00 + Wc + 1) * 3 + c] : 0;
+            const int res = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11 + (1 << 14)) >> 15;
+            const float v = m * (float)res + (1.f - m) * (float)px[k * 3 + c];
+            px[k * 3 + c] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
+        }
+    }
+    out[0] = wv[0]; out[1] = wv[1]; out[2] = wv[2];
+}
+
 // float image (one channel) warped into the destination frame (prepare_paste_back, crop.py:515-521)
 __global__ void __launch_bounds__(256) warp_f32_kernel(const float* __restrict__ src, int Hs, int Ws, AffineInv A, float* __restrict__ dst,
                                                        int Hd, int Wd)
@@ -250,5 +340,27 @@ int launch_warp_f32(const float* src, int Hs, int Ws, const double M[6], float* 
     const long n = (long)Hd * Wd;
     hipLaunchKernelGGL(warp_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, Hs, Ws, invert_affine(M), dst, Hd, Wd);
     LAUNCH_CHECK("warp_f32");
+    return 0;
+}
+
+int launch_paste_batch(const unsigned char* crops, const float* masks, int Hc, int Wc, const double* M, const unsigned char* oris,
+                       unsigned char* outs, int B, int Ho, int Wo, hipStream_t st)
+{
+    const long P = (long)Ho * Wo;
+    const bool vec = Wo % 4 == 0 && ((uintptr_t)oris & 3) == 0 && ((uintptr_t)outs & 3) == 0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int nb = B - b0 < 64 ? B - b0 : 64;
+        if (vec) {
+            AffineBatch AB;
+            for (int i = 0; i < nb; ++i) AB.a[i] = invert_affine(M + (long)(b0 + i) * 6);
+            hipLaunchKernelGGL(paste_batch_kernel, dim3((unsigned)((P / 4 + 255) / 256), nb), dim3(256), 0, st, crops + (long)b0 * Hc * Wc * 3,
+                               masks + (long)b0 * Hc * Wc, Hc, Wc, AB, oris + (long)b0 * P * 3, outs + (long)b0 * P * 3, Ho, Wo);
+            LAUNCH_CHECK("paste_batch");
+        } else {      // odd widths / unaligned buffers: the single-frame kernel per frame (same arithmetic)
+            for (int i = b0; i < b0 + nb; ++i)
+                if (launch_paste(crops + (long)i * Hc * Wc * 3, masks + (long)i * Hc * Wc, nullptr, Hc, Wc, M + (long)i * 6, oris + (long)i * P * 3,
+                                 outs + (long)i * P * 3, Ho, Wo, st)) return -1;
+        }
+    }
     return 0;
 }

@@ -244,6 +244,63 @@ __global__ void __launch_bounds__(256) m_head_kernel(const float* __restrict__ x
     }
 }
 
+
+// Key-points of B frames from the raw head outputs, on the device ("transform_keypoint on-device"):
+// can_swapper.get_kp_info's refinement (can_swap_e2e.py:192-197: 66-bin logits -> degrees, camera.py:14-28), get_rotation_matrix
+// (camera.py:31-73: R = (Rz Ry Rx)^T of the angles in radians) and transform_keypoint (can_swap_e2e.py:228-256):
+//     x_t = scale * (kp R + exp) + (t_x, t_y, 0),     x_can = scale * kp   (can_swap_pipeline_e2e.py:243)
+// raw: [B][328] in the order kp(63) scale(1) pitch(66) yaw(66) roll(66) t(3) exp(63).  One wavefront per frame.
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float bins_to_degree(const float* logits, int lane)      // sum(softmax(logits) * idx) * 3 - 97.5
+{
+    const float a = logits[lane], b = lane < 2 ? logits[64 + lane] : -INFINITY;
+    const float m = wave_max(fmaxf(a, b));
+    const float ea = expf(a - m), eb = lane < 2 ? expf(b - m) : 0.f;
+    const float den = wave_sum(ea + eb);
+    const float num = wave_sum(ea / den * (float)lane + eb / den * (float)(64 + lane));
+    return num * 3.f - 97.5f;
+}
+
+__global__ void __launch_bounds__(64) m_keypoints_kernel(const float* __restrict__ raw, float* __restrict__ x_t, float* __restrict__ x_can,
+                                                         float* __restrict__ rot_out)
+{
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float* r = raw + (long)n * 328;
+    const float PI = 3.14159265358979323846f;
+    const float x = bins_to_degree(r + 64, lane) / 180.f * PI, y = bins_to_degree(r + 130, lane) / 180.f * PI,
+                z = bins_to_degree(r + 196, lane) / 180.f * PI;
+    const float cx = cosf(x), sx = sinf(x), cy = cosf(y), sy = sinf(y), cz = cosf(z), sz = sinf(z);
+    // rz @ ry, then @ rx (camera.py:53-71), row-major m[i][j]
+    const float zy[3][3] = {{cz * cy, -sz, cz * sy}, {sz * cy, cz, sz * sy}, {-sy, 0.f, cy}};
+    float m[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        m[i][0] = zy[i][0];
+        m[i][1] = zy[i][1] * cx + zy[i][2] * sx;
+        m[i][2] = zy[i][1] * -sx + zy[i][2] * cx;
+    }
+    // R = m^T: (kp R)_j = sum_i kp_i R[i][j] = sum_i kp_i m[j][i]
+    if (rot_out && lane < 9) rot_out[(long)n * 9 + lane] = m[lane % 3][lane / 3];
+    if (lane >= 21) return;
+    const float scale = r[63];
+    const float k0 = r[lane * 3], k1 = r[lane * 3 + 1], k2 = r[lane * 3 + 2];
+    const float* ex = r + 265 + lane * 3;
+    float* xt = x_t + ((long)n * 21 + lane) * 3;
+    float* xc = x_can + ((long)n * 21 + lane) * 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float v = ((k0 * m[j][0] + k1 * m[j][1]) + k2 * m[j][2] + ex[j]) * scale;
+        xt[j] = j < 2 ? v + r[262 + j] : v;
+    }
+    xc[0] = scale * k0; xc[1] = scale * k1; xc[2] = scale * k2;
+}
+
 }  // namespace
 
 #define M_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { cs_set_error(name ": %s", hipGetErrorString(e_)); return -1; } } while (0)
@@ -301,5 +358,12 @@ int launch_m_head(const float* x, const float* g, const float* be, const float* 
 {
     hipLaunchKernelGGL(m_head_kernel, dim3(N), dim3(256), 0, st, x, g, be, hw, hb, out, P);
     M_LAUNCH_CHECK("m_head");
+    return 0;
+}
+
+int launch_m_keypoints(const float* raw, float* x_t, float* x_can, float* rot, int N, hipStream_t st)
+{
+    hipLaunchKernelGGL(m_keypoints_kernel, dim3(N), dim3(64), 0, st, raw, x_t, x_can, rot);
+    M_LAUNCH_CHECK("m_keypoints");
     return 0;
 }

@@ -57,6 +57,47 @@ class SoftErosion:
     forward = __call__
 
 
+def soft_erosion_frames(e: Engine, masks, weight, kernel_size=21, threshold=0.9, iterations=3, out=None):
+    """B independent SoftErosion calls (the pipeline's loop calls the module once per frame, can_swap_pipeline_e2e.py:274: the maximum of
+    crop.py:45 is that frame's) in one launch sequence.  masks: (B,H,W) uint8 0/1 labels or fp32, on the device -> soft masks (B,H,W) fp32."""
+    m = torch.as_tensor(masks)
+    if m.dim() == 4 and m.shape[1] == 1:
+        m = m[:, 0]
+    if m.dim() != 3:
+        raise ValueError("soft_erosion_frames expects (B, H, W) masks")
+    if m.dtype not in (torch.uint8, torch.float32):
+        m = m.to(torch.uint8) if not m.dtype.is_floating_point else m.float()
+    m = m.to(e.device).contiguous()
+    B, H, W = m.shape
+    soft = torch.empty((B, H, W), dtype=torch.float32, device=e.device) if out is None else out
+    with torch.cuda.device(e.device):
+        _lib.check(e.lib.cs_soft_erosion_frames(e.h, B, H, W, _ptr(m), int(m.dtype == torch.uint8), _ptr(weight), kernel_size, float(threshold),
+                                                iterations, _ptr(soft), None, e._stream()), "cs_soft_erosion_frames")
+    return soft
+
+
+def paste_back_batch(e: Engine, crops, masks_crop, M_c2o, imgs_ori, out=None):
+    """prepare_paste_back + paste_back (crop.py:515-529) of B frames in one launch: crops (B,Hc,Wc,3) u8, masks_crop (B,Hc,Wc) fp32 soft masks
+    in the crop frame, M_c2o (B,2,3) or (B,3,3) host matrices crop -> original, imgs_ori (B,Ho,Wo,3) u8 -> (B,Ho,Wo,3) u8."""
+    crops, ori = torch.as_tensor(crops), torch.as_tensor(imgs_ori)
+    if crops.dtype != torch.uint8 or crops.dim() != 4 or crops.shape[3] != 3 or ori.dtype != torch.uint8 or ori.dim() != 4 or ori.shape[3] != 3:
+        raise ValueError("expected BxHxWx3 uint8 crops and original frames")
+    crops, ori = crops.to(e.device).contiguous(), ori.to(e.device).contiguous()
+    B = crops.shape[0]
+    mc = torch.as_tensor(masks_crop).to(e.device).float().contiguous()
+    if tuple(mc.shape) != tuple(crops.shape[:3]) or ori.shape[0] != B:
+        raise ValueError("masks_crop must be (B, Hc, Wc) and imgs_ori must hold B frames")
+    M = np.ascontiguousarray(np.asarray(M_c2o, dtype=np.float64).reshape(B, -1)[:, :6])
+    if out is None:
+        out = torch.empty_like(ori)
+    elif out.dtype != torch.uint8 or tuple(out.shape) != tuple(ori.shape) or not out.is_contiguous() or out.device != ori.device:
+        raise ValueError("out must be a contiguous uint8 tensor of the shape of imgs_ori on the engine's device")
+    with torch.cuda.device(e.device):
+        _lib.check(e.lib.cs_paste_back_batch(e.h, B, _ptr(crops), _ptr(mc), crops.shape[1], crops.shape[2], M.ctypes.data_as(C.POINTER(C.c_double)),
+                                             _ptr(ori), _ptr(out), ori.shape[1], ori.shape[2], e._stream()), "cs_paste_back_batch")
+    return out
+
+
 def _u8_hwc(e: Engine, img):
     t = torch.as_tensor(img)
     if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:

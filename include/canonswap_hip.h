@@ -26,7 +26,7 @@ typedef struct cs_engine cs_engine;
 int cs_create(int device_id, int max_batch, cs_engine** out);   /* 1 <= max_batch <= 84 (32-bit element offsets inside one tensor); workspace ~0.35 GB per frame of batch; 64 is the fastest launch size (profiles/r05_b_batch_sweep.txt) */
 void cs_destroy(cs_engine* e);
 const char* cs_last_error(void);
-#define CS_ABI_VERSION 3       /* bumped whenever a struct of this header, an entry point's meaning or the weight blob format changes */
+#define CS_ABI_VERSION 4       /* bumped whenever a struct of this header, an entry point's meaning or the weight blob format changes */
 int cs_abi_version(void);
 /* Upload one packed weight blob (host pointer).  Names/layouts are produced by canonswap_amd/pack.py from
  * the reference's state-dict keys (BatchNorm / spectral norm folded, channels-last, fp16 MFMA order). */
@@ -112,6 +112,22 @@ int cs_warp_affine_f32(cs_engine* e, const float* src, int Hs, int Ws, const dou
  * out = clip(mask * warp(crop) + (1 - mask) * img_ori, 0, 255) truncated to 8 bits */
 int cs_paste_back(cs_engine* e, const uint8_t* crop, const float* mask_crop, const float* mask_ori, int Hc, int Wc,
                   const double M_c2o[6], const uint8_t* img_ori, uint8_t* out, int Ho, int Wo, void* stream);
+
+/* The same steps for the B frames of one launch of the per-frame loop (can_swap_pipeline_e2e.py:273-283 runs them frame by frame):
+ * cs_soft_erosion_frames = B independent SoftErosion calls on (1,1,H,W) masks - the maximum of crop.py:45 is taken per frame, as in the
+ * pipeline's loop, not over the batch; masks: BxHxW, fp32 or (masks_u8 != 0) uint8 0/1 labels (`torch.isin(labels, valid).to(int)`,
+ * can_swap_pipeline_e2e.py:192).  cs_paste_back_batch = prepare_paste_back + paste_back of B frames in one launch: crops BxHcxWcx3 u8
+ * (the generator's frames), masks_crop BxHcxWc fp32 (the soft masks, in the crop frame), M_c2o: HOST, B x 6 doubles (2x3 row major, crop ->
+ * original, target_M_c2o_lst[i]), imgs_ori / out BxHoxWox3 u8. */
+int cs_soft_erosion_frames(cs_engine* e, int B, int H, int W, const void* masks, int masks_u8, const float* w, int ksize, float thr, int iters,
+                           float* soft_out, uint8_t* hard_out, void* stream);
+int cs_paste_back_batch(cs_engine* e, int B, const uint8_t* crops, const float* masks_crop, int Hc, int Wc, const double* M_c2o,
+                        const uint8_t* imgs_ori, uint8_t* out, int Ho, int Wo, void* stream);
+/* Key-points of B frames from cs_motion_extract's raw head outputs, on the device: get_kp_info's refinement (can_swap_e2e.py:192-197,
+ * camera.py:14-28), get_rotation_matrix (camera.py:31-73) and transform_keypoint (can_swap_e2e.py:228-256) -> x_t Bx21x3
+ * = scale (kp R + exp) + t_xy, and x_can = scale kp Bx21x3 (can_swap_pipeline_e2e.py:243); rot (Bx3x3, may be NULL) = R.
+ * Replaces make_motion_template's per-frame D2H of seven tensors (can_swap_pipeline_e2e.py:111-125). */
+int cs_motion_keypoints(cs_engine* e, int B, const float* raw, float* x_t, float* x_can, float* rot, void* stream);
 
 /* ---- measurement: per-kernel-family HIP-event timing on the launch stream */
 int cs_profile_begin(cs_engine* e);

@@ -71,7 +71,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert declared == set(_lib.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.cs_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.cs_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_isa_check_of_the_hand_counted_weight_rings():
