@@ -1026,7 +1026,7 @@ int run_M(cs_engine* e, int B, const float* img, float* out, hipStream_t st)
     if (!e->m_x) {   // workspace on first use
         const size_t P0 = (size_t)e->maxB * 64 * 64;
         if (e->alloc(&e->m_x, P0 * 96) || e->alloc(&e->m_y, P0 * 96 * 3) || e->alloc(&e->m_h, P0 * 384 * 3) || e->alloc(&e->m_h32, P0 * 384) ||
-            e->alloc(&e->m_sumsq, (size_t)e->maxB * 3072) || e->alloc(&e->m_scale, (size_t)e->maxB * 3072)) return -1;
+            e->alloc(&e->m_sumsq, (size_t)e->maxB * 3072 * 16) || e->alloc(&e->m_scale, (size_t)e->maxB * 3072)) return -1;
     }
     TRY(e->run(1, st, [&] { return launch_m_stem(img, e->m_stem_w, e->m_stem_b, e->m_stem_g, e->m_stem_be, e->m_x, B, 256, 256, st); }, "m_stem"));
     int H = 64;

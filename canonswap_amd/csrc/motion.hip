@@ -50,28 +50,69 @@ __device__ __forceinline__ void wave_layernorm(float (&v)[K], int C, int lane, f
 
 // stem: Conv2d(3, 96, k=4, s=4) + LayerNorm(channels_first) (convnextv2.py:64-68). img fp32 NCHW -> x fp32 NHWC.
 // w: [48][96] with k = ci*16 + dy*4 + dx.
+// Round 6: a workgroup owns one output row (n, ho) of 64 positions: the 3 x 4 input rows (12 KB) and the weights (18 KB) are staged in LDS
+// with coalesced loads; thread = (position, 24-channel group), the four groups of a position in four waves, so the weight reads are
+// wave-uniform LDS broadcasts and an input patch row is one ds_read_b128.  (Before: one wavefront per position issuing 48 dependent
+// scalar loads - 0.62 ms per 64 frames for 150 MB of traffic.)  LayerNorm: two-pass (mean, then deviations) through LDS, fixed order.
 __global__ void __launch_bounds__(256) m_stem_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ b,
                                                      const float* __restrict__ g, const float* __restrict__ be, float* __restrict__ x,
                                                      int N, int HI, int WI)
 {
-    const int lane = threadIdx.x & 63;
-    const int HO = HI / 4, WO = WI / 4;
-    const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pos >= (long)N * HO * WO) return;
-    const int wo = pos % WO, ho = (pos / WO) % HO, n = pos / ((long)WO * HO);
-    float v[2] = {0.f, 0.f};
-    for (int k = 0; k < 48; ++k) {
-        const int ci = k >> 4, dy = (k >> 2) & 3, dx = k & 3;
-        const float a = img[(((long)n * 3 + ci) * HI + ho * 4 + dy) * WI + wo * 4 + dx];      // wave-uniform -> scalar load
-        v[0] = fmaf(a, w[k * 96 + lane], v[0]);
-        if (lane < 32) v[1] = fmaf(a, w[k * 96 + 64 + lane], v[1]);
+    constexpr int WO = 64, CG = 24;
+    __shared__ __attribute__((aligned(16))) float in_s[12][WO * 4];      // [ci*4 + dy][input column]
+    __shared__ __attribute__((aligned(16))) float w_s[48 * 96];
+    __shared__ float red[4][WO];
+    const int HO = HI / 4;
+    const int ho = blockIdx.x % HO, n = blockIdx.x / HO;
+    const int t = threadIdx.x;
+    for (int i = t; i < 12 * WO; i += 256) {                            // 12 rows of 256 floats, float4 per thread
+        const int r = i / WO, c4 = i % WO, ci = r >> 2, dy = r & 3;
+        ((float4*)in_s[r])[c4] = ((const float4*)(img + (((long)n * 3 + ci) * HI + ho * 4 + dy) * WI))[c4];
     }
-    v[0] += b[lane];
-    if (lane < 32) v[1] += b[64 + lane];
-    wave_layernorm<2>(v, 96, lane, 1e-6f);
-    float* o = x + pos * 96;
-    o[lane] = v[0] * g[lane] + be[lane];
-    if (lane < 32) o[64 + lane] = v[1] * g[64 + lane] + be[64 + lane];
+    for (int i = t; i < 48 * 96 / 4; i += 256) ((float4*)w_s)[i] = ((const float4*)w)[i];
+    __syncthreads();
+    const int wo = t & 63, cg = t >> 6;
+    float v[CG];
+#pragma unroll
+    for (int j = 0; j < CG; ++j) v[j] = b[cg * CG + j];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+        const float4 a4 = ((const float4*)in_s[r])[wo];
+        const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const float4* wr = (const float4*)(w_s + (r * 4 + dx) * 96 + cg * CG);
+#pragma unroll
+            for (int j4 = 0; j4 < CG / 4; ++j4) {
+                const float4 q = wr[j4];
+                v[4 * j4] = fmaf(a[dx], q.x, v[4 * j4]); v[4 * j4 + 1] = fmaf(a[dx], q.y, v[4 * j4 + 1]);
+                v[4 * j4 + 2] = fmaf(a[dx], q.z, v[4 * j4 + 2]); v[4 * j4 + 3] = fmaf(a[dx], q.w, v[4 * j4 + 3]);
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) s += v[j];
+    red[cg][wo] = s;
+    __syncthreads();
+    const float mean = ((red[0][wo] + red[1][wo]) + (red[2][wo] + red[3][wo])) / 96.f;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) { const float d = v[j] - mean; q += d * d; }
+    red[cg][wo] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[0][wo] + red[1][wo]) + (red[2][wo] + red[3][wo])) / 96.f + 1e-6f);
+    float* o = x + (((long)n * HO + ho) * WO + wo) * 96 + cg * CG;
+#pragma unroll
+    for (int j4 = 0; j4 < CG / 4; ++j4) {
+        float4 r4;
+        r4.x = (v[4 * j4] - mean) * rstd * g[cg * CG + 4 * j4] + be[cg * CG + 4 * j4];
+        r4.y = (v[4 * j4 + 1] - mean) * rstd * g[cg * CG + 4 * j4 + 1] + be[cg * CG + 4 * j4 + 1];
+        r4.z = (v[4 * j4 + 2] - mean) * rstd * g[cg * CG + 4 * j4 + 2] + be[cg * CG + 4 * j4 + 2];
+        r4.w = (v[4 * j4 + 3] - mean) * rstd * g[cg * CG + 4 * j4 + 3] + be[cg * CG + 4 * j4 + 3];
+        ((float4*)o)[j4] = r4;
+    }
 }
 
 // Block front half: depth-wise 7x7 conv (padding 3) + LayerNorm (convnextv2.py:36-38); x fp32 -> y split fp16 [N][H][W][3C].
@@ -79,11 +120,17 @@ __global__ void __launch_bounds__(256) m_stem_kernel(const float* __restrict__ i
 // every input element of the 7 x (DWP+6) window is loaded once and scattered into the outputs it feeds (4x fewer loads than
 // a window per position), the 7 weights of the current kernel row sit in registers.
 constexpr int DWP = 8;
+// Round 6: the loads of a kernel row (14 input columns + 7 weights per 64-channel group) are issued together, from clamped addresses with a
+// select behind them, before the row's FMAs: the branchy form (a bounds test in front of every load) made hipcc wait for each load's round
+// trip in turn - 98 x K dependent latencies per wavefront, 0.28 ms per stage-0 launch for 250 MB.  Channel groups go through in chunks of
+// at most 3 (registers); an output's products are still added in the order (dy, dx) ascending: the same bits as before.
 template <int K>
 __global__ void __launch_bounds__(256) m_dwln_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ b,
                                                      const float* __restrict__ g, const float* __restrict__ be, half_t* __restrict__ y,
                                                      int N, int H, int W, int C)
 {
+    constexpr int KC = K > 3 ? 3 : K;
+    static_assert(K % KC == 0, "channel groups per chunk");
     const int lane = threadIdx.x & 63;
     const int runs_per_row = W / DWP;                                   // W is 64, 32, 16 or 8
     const long run = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -94,29 +141,53 @@ __global__ void __launch_bounds__(256) m_dwln_kernel(const float* __restrict__ x
     for (int p = 0; p < DWP; ++p)
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[p][k] = (lane + 64 * k < C) ? b[lane + 64 * k] : 0.f;
-    for (int dy = 0; dy < 7; ++dy) {
-        const int h = h0 + dy - 3;
-        if ((unsigned)h >= (unsigned)H) continue;
-        float wk[7][K];
 #pragma unroll
-        for (int dx = 0; dx < 7; ++dx)
+    for (int kc = 0; kc < K; kc += KC) {
+#pragma unroll 1
+        for (int dy = 0; dy < 7; ++dy) {
+            const int h = h0 + dy - 3;
+            if ((unsigned)h >= (unsigned)H) continue;                   // wave-uniform
+            float wk[7][KC], xv[DWP + 6][KC];
 #pragma unroll
-            for (int k = 0; k < K; ++k) wk[dx][k] = (lane + 64 * k < C) ? wt[(dy * 7 + dx) * C + lane + 64 * k] : 0.f;
-        const float* xrow = x + ((long)n * H + h) * W * C;
+            for (int dx = 0; dx < 7; ++dx)
 #pragma unroll
-        for (int j = 0; j < DWP + 6; ++j) {                             // input column w0 - 3 + j feeds output p with tap dx = j - p
-            const int ww = w0 - 3 + j;
-            if ((unsigned)ww >= (unsigned)W) continue;
-            float xv[K];
+                for (int k = 0; k < KC; ++k) {
+                    const int c = lane + 64 * (kc + k);
+                    wk[dx][k] = wt[(dy * 7 + dx) * C + (c < C ? c : 0)];
+                }
+            const float* xrow = x + ((long)n * H + h) * W * C;
 #pragma unroll
-            for (int k = 0; k < K; ++k) xv[k] = (lane + 64 * k < C) ? xrow[(long)ww * C + lane + 64 * k] : 0.f;
+            for (int j = 0; j < DWP + 6; ++j) {                         // input column w0 - 3 + j feeds output p with tap dx = j - p
+                const int ww = w0 - 3 + j;
+                const int wc = (unsigned)ww < (unsigned)W ? ww : w0;
 #pragma unroll
-            for (int p = 0; p < DWP; ++p) {
-                const int dx = j - p;
-                if (dx < 0 || dx > 6) continue;
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc[p][k] = fmaf(xv[k], wk[dx][k], acc[p][k]);
+                for (int k = 0; k < KC; ++k) {
+                    const int c = lane + 64 * (kc + k);
+                    xv[j][k] = xrow[(long)wc * C + (c < C ? c : 0)];
+                }
             }
+            // The loads above must stay unconditional and together: with the selects below applied directly to the loaded values hipcc
+            // sinks each load under its select's condition - a branch over the load and an s_waitcnt vmcnt(0) behind it, one round trip
+            // after the other.  The opaque moves pin "loaded value" as an unconditional use AFTER all loads have been issued.
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+                for (int k = 0; k < KC; ++k) asm volatile("" : "+v"(wk[dx][k]));
+#pragma unroll
+            for (int j = 0; j < DWP + 6; ++j) {
+                const bool in = (unsigned)(w0 - 3 + j) < (unsigned)W;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    asm volatile("" : "+v"(xv[j][k]));
+                    xv[j][k] = (in && lane + 64 * (kc + k) < C) ? xv[j][k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < DWP; ++p)
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) acc[p][kc + k] = fmaf(xv[p + dx][k], wk[dx][k], acc[p][kc + k]);
         }
     }
 #pragma unroll
@@ -154,30 +225,57 @@ __global__ void __launch_bounds__(256) m_ln_s2d_kernel(const float* __restrict__
         if (lane + 64 * k < C) store_split(o, 4 * C, sub + lane + 64 * k, v[k] * g[lane + 64 * k] + be[lane + 64 * k]);
 }
 
-// GRN statistics (util.py:365-367): sumsq[n][c] = sum over the P positions of h[n][p][c]^2. Block = 64 channels x 4 position lanes.
+// GRN statistics (util.py:365-367): sumsq[n][z][c] = sum over the z-th slice of the P positions of h[n][p][c]^2.
+// Round 6: a workgroup = 64 channels (16 threads x float4) x 16 position lanes, four loads in flight per thread, and the positions of a
+// sample are cut into gridDim.z slices (a fixed function of P): 384 workgroups of 1024 dependent loads each ran at 0.95 TB/s on stage 0.
+// The slices are added by m_grn_scale_kernel in ascending order: deterministic.
+constexpr int GRN_MAXZ = 16;
 __global__ void __launch_bounds__(256) m_grn_sumsq_kernel(const float* __restrict__ h, float* __restrict__ sumsq, int P, int C)
 {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, n = blockIdx.y;
-    float s = 0.f;
-    for (int p = pl; p < P; p += 4) {
-        const float v = h[((long)n * P + p) * C + c];
-        s = fmaf(v, v, s);
+    __shared__ float4 red[16][16];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4, n = blockIdx.y, nz = gridDim.z;
+    const int per = (P + nz - 1) / nz, p0 = blockIdx.z * per, p1 = min(P, p0 + per);
+    const float* base = h + (long)n * P * C + c;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = p0 + pl;
+    for (; p + 48 < p1; p += 64) {
+        const float4 a0 = *(const float4*)(base + (long)p * C), a1 = *(const float4*)(base + (long)(p + 16) * C);
+        const float4 a2 = *(const float4*)(base + (long)(p + 32) * C), a3 = *(const float4*)(base + (long)(p + 48) * C);
+        s.x = fmaf(a0.x, a0.x, s.x); s.y = fmaf(a0.y, a0.y, s.y); s.z = fmaf(a0.z, a0.z, s.z); s.w = fmaf(a0.w, a0.w, s.w);
+        s.x = fmaf(a1.x, a1.x, s.x); s.y = fmaf(a1.y, a1.y, s.y); s.z = fmaf(a1.z, a1.z, s.z); s.w = fmaf(a1.w, a1.w, s.w);
+        s.x = fmaf(a2.x, a2.x, s.x); s.y = fmaf(a2.y, a2.y, s.y); s.z = fmaf(a2.z, a2.z, s.z); s.w = fmaf(a2.w, a2.w, s.w);
+        s.x = fmaf(a3.x, a3.x, s.x); s.y = fmaf(a3.y, a3.y, s.y); s.z = fmaf(a3.z, a3.z, s.z); s.w = fmaf(a3.w, a3.w, s.w);
     }
-    red[pl][cl] = s;
+    for (; p < p1; p += 16) {
+        const float4 a0 = *(const float4*)(base + (long)p * C);
+        s.x = fmaf(a0.x, a0.x, s.x); s.y = fmaf(a0.y, a0.y, s.y); s.z = fmaf(a0.z, a0.z, s.z); s.w = fmaf(a0.w, a0.w, s.w);
+    }
+    red[pl][cq] = s;
     __syncthreads();
-    if (pl == 0) sumsq[(long)n * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (pl == 0) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) { const float4 q = red[i][cq]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+        *(float4*)(sumsq + ((long)n * nz + blockIdx.z) * C + c) = t;
+    }
 }
 
 // scale[n][c] = 1 + gamma[c] * Gx / (mean_c(Gx) + 1e-6), Gx = sqrt(sumsq)  (util.py:366-368: gamma*(x*Nx) + beta + x)
 __global__ void __launch_bounds__(256) m_grn_scale_kernel(const float* __restrict__ sumsq, const float* __restrict__ gamma,
-                                                          float* __restrict__ scale, int C)
+                                                          float* __restrict__ scale, int C, int nz)
 {
     __shared__ float red[256];
+    __shared__ float gx[3072];
     const int n = blockIdx.x;
     float s = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) s += sqrtf(sumsq[(long)n * C + c]);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float q = 0.f;
+        for (int z = 0; z < nz; ++z) q += sumsq[((long)n * nz + z) * C + c];
+        const float r = sqrtf(q);
+        gx[c] = r;
+        s += r;
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
@@ -185,7 +283,7 @@ __global__ void __launch_bounds__(256) m_grn_scale_kernel(const float* __restric
         __syncthreads();
     }
     const float inv = 1.f / (red[0] / (float)C + 1e-6f);
-    for (int c = threadIdx.x; c < C; c += 256) scale[(long)n * C + c] = 1.f + gamma[c] * sqrtf(sumsq[(long)n * C + c]) * inv;
+    for (int c = threadIdx.x; c < C; c += 256) scale[(long)n * C + c] = 1.f + gamma[c] * gx[c] * inv;
 }
 
 // out[pos] = split(h * scale[n][c] + beta[c]): fp32 [N][P][C] -> split fp16 [N][P][3C], 4 channels per thread
@@ -307,8 +405,8 @@ __global__ void __launch_bounds__(64) m_keypoints_kernel(const float* __restrict
 
 int launch_m_stem(const float* img, const float* w, const float* b, const float* g, const float* be, float* x, int N, int HI, int WI, hipStream_t st)
 {
-    const long pos = (long)N * (HI / 4) * (WI / 4);
-    hipLaunchKernelGGL(m_stem_kernel, dim3((unsigned)((pos + 3) / 4)), dim3(256), 0, st, img, w, b, g, be, x, N, HI, WI);
+    if (WI != 256 || HI % 4) { cs_set_error("m_stem: 256 input columns (got %d x %d)", HI, WI); return -1; }
+    hipLaunchKernelGGL(m_stem_kernel, dim3((unsigned)((long)N * (HI / 4))), dim3(256), 0, st, img, w, b, g, be, x, N, HI, WI);
     M_LAUNCH_CHECK("m_stem");
     return 0;
 }
@@ -343,10 +441,11 @@ int launch_m_ln_s2d(const float* x, const float* g, const float* be, half_t* y, 
 
 int launch_m_grn(const float* h, const float* gamma, const float* beta, float* sumsq, float* scale, half_t* out, int N, int P, int C, hipStream_t st)
 {
-    if (C % 64) { cs_set_error("m_grn: unsupported C=%d", C); return -1; }
-    hipLaunchKernelGGL(m_grn_sumsq_kernel, dim3(C / 64, N), dim3(256), 0, st, h, sumsq, P, C);
+    if (C % 64 || C > 3072) { cs_set_error("m_grn: unsupported C=%d", C); return -1; }
+    const int nz = P >= 4096 ? 16 : P >= 1024 ? 8 : P >= 256 ? 4 : 1;      // position slices per sample: a function of P only (sumsq holds N x GRN_MAXZ x C floats)
+    hipLaunchKernelGGL(m_grn_sumsq_kernel, dim3(C / 64, N, nz), dim3(256), 0, st, h, sumsq, P, C);
     M_LAUNCH_CHECK("m_grn_sumsq");
-    hipLaunchKernelGGL(m_grn_scale_kernel, dim3(N), dim3(256), 0, st, sumsq, gamma, scale, C);
+    hipLaunchKernelGGL(m_grn_scale_kernel, dim3(N), dim3(256), 0, st, sumsq, gamma, scale, C, nz);
     M_LAUNCH_CHECK("m_grn_scale");
     const long total4 = (long)N * P * C / 4;
     hipLaunchKernelGGL(m_grn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, h, scale, beta, out, (long)P * C, C, total4);
