@@ -447,12 +447,25 @@ def main():
         del gen_u8
 
     # ---- roofline of the dominant kernel family (conv_halo_kernel): HIP events around every launch, same workload
-    prof = None
+    prof, sparse_ms, sparse_n = None, 0.0, 0
     if rank == 0:
+        import csv as _csv2
+        import tempfile as _tf
+        ptmp = _tf.NamedTemporaryFile(suffix=".csv", delete=False); ptmp.close()
+        user_csv = os.environ.get("CANONSWAP_PROFILE_CSV")
+        if user_csv is None:                                 # per-launch records of this pass: the sparse-motion sampler's own row (below)
+            os.environ["CANONSWAP_PROFILE_CSV"] = ptmp.name
         eng.profile_begin()
         for i in range(K):
             step(plan, i)
         prof = eng.profile_end()
+        if user_csv is None:
+            del os.environ["CANONSWAP_PROFILE_CSV"]
+        with open(user_csv or ptmp.name) as f:
+            for row in _csv2.DictReader(f):
+                if row["label"] == "dm_sparse":
+                    sparse_ms += float(row["ms"]); sparse_n += 1
+        os.remove(ptmp.name)
     if distd:
         dist.barrier()
 
@@ -569,6 +582,15 @@ def main():
                               "frac": round(WARP_BYTES_PER_FRAME * plan.n_local * K / (prof["warp_ms"] / 1e3) / 8e12, 4),
                               "avg_launch_us": round(prof["warp_ms"] * 1e3 / max(prof["warp_launches"], 1), 2), "traffic": warp_traffic,
                               "traffic_unit": "HBM bytes per warp launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)"},
+            # the other HBM row SURVEY 8d names: the sparse-motion sampler (dense_motion.py:29-65: 22 deformed copies of the 4-channel compressed
+            # volume + 22 heat maps, concatenated) - per call 4 x 65536 x 2 B read + 22 x 4 x 65536 x 2 B written (the 17 MB grid is generated from
+            # the 21 key-points, never read) = 12.06 MB at 2-byte storage; two calls per frame
+            "sparse_roofline": {"bound": "hbm", "kernel": "dm_sparse_kernel (sparse motions + deformed features + heat maps + concat into the hourglass input)",
+                                "algorithmic_mb_per_call": 12.06, "calls_per_frame": 2,
+                                "achieved": round(12.06e6 * 2 * K * plan.n_local / max(sparse_ms, 1e-9) / 1e6, 1) if sparse_n else None,
+                                "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(12.06e6 * 2 * K * plan.n_local / max(sparse_ms, 1e-9) / 1e6 / 8000.0, 4) if sparse_n else None,
+                                "avg_launch_us": round(sparse_ms * 1e3 / sparse_n, 2) if sparse_n else None},
             "cpu_baseline": cpu,
         }
         if parity:

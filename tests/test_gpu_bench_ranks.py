@@ -97,3 +97,19 @@ def test_rccl_world_of_one_weak_scaling_line_and_stream_subcommunicators(tmp_pat
     assert two["backend"] == "nccl"
     for s in range(2):
         assert json.load(open(f"{c1}.s{s}")) == json.load(open(f"{c2}.s{s}"))
+
+
+def test_configs3_job_shape_through_rccl_equals_the_plain_run(tmp_path):
+    """the BASELINE configs[3] job at its real size on the one GPU a box has - 1200 frames in launches of 64 (19 chunks, the
+    last one ragged), the 943 MB receive buffer on the device, every chunk pushed through an asynchronous RCCL gather inside the timed region -
+    CRC-equal, frame by frame, to the run without a process group.  The two frames/s figures (with and without the gather on the leader) are
+    printed for profiles/."""
+    common = ["--frames", "1200", "--batch", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    crc1, crc2 = str(tmp_path / "plain.json"), str(tmp_path / "rccl.json")
+    one = _run([sys.executable, "bench.py", "--gpus", "1", *common, "--dump-crc", crc1])
+    two = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", *common, "--dump-crc", crc2])
+    assert two["backend"] == "nccl" and "gather" in two["collectives"] and two["config"]["frames_total"] == 1200
+    a, b = json.load(open(crc1)), json.load(open(crc2))
+    assert len(a) == 1200 and a == b
+    print(f"configs[3] shape on 1 GPU: {one['value']:.1f} frames/s plain, {two['value']:.1f} frames/s with the chunked RCCL gather into the "
+          f"device receive buffer ({two['value'] / one['value']:.4f})")
