@@ -350,7 +350,10 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
         // channel part of the source offset; grouped mode: chunk j -> group j / cg at stride in_sG
         long coff = c0;
         int climit = p.Cin - c0;                 // channels of this chunk that exist
-        if (CK == 32 && p.cg > 0) {
+        // (64-channel chunks: the 1x1 kernels and the dynamic-shape ones they fall back to on small maps, with an even cg - the two
+        // 32-channel halves of a chunk are then neighbours in memory; the launcher checks.  Compiled into nothing else: the 128 x 256
+        // kernels with hand-counted rings tolerate no addition, DESIGN 5.6 rule 9)
+        if ((CK == 32 || ST == 15 || (ST == 0 && WCH != 4)) && p.cg > 0) {
             const int j = c0 >> 5;
             coff = (long)(j / p.cg) * p.in_sG + (j % p.cg) * 32;
             climit = p.cg_cin - (j % p.cg) * 32;
@@ -1195,6 +1198,10 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
         }
     }
     if (p.wslot && (1 << lgS) != BM) { cs_set_error("conv_halo: per-sample weight sets need tiles within one sample"); return -1; }
+    if (p.cg > 0 && CK != 32 && (!(ST == 15 || (ST == 0 && WCH != 4)) || (p.cg & 1) || (p.in_sG & 63) || p.KD * p.KH * p.KW != 1)) {
+        cs_set_error("conv_halo: grouped input channels run 32-channel chunks (64-channel chunks: 1x1 convs with an even number of 32-channel pieces per group)");
+        return -1;
+    }
     const int TN = BM >> lgS;
     const long HV = (long)TN * ((1 << p.lgTD) + p.KD - 1) * ((1 << p.lgTH) + p.KH - 1) * ((1 << p.lgTW) + p.KW - 1);
     const int nck = (p.Cin + CK - 1) / CK;

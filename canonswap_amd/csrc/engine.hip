@@ -95,7 +95,7 @@ struct cs_engine {
     struct MStage { int C, n; MBlk blk[9]; const float *ds_g, *ds_b; ConvL ds; } m_st[4];
     const float *m_norm_g = nullptr, *m_norm_b = nullptr, *m_head_w = nullptr, *m_head_b = nullptr;
     float *m_x = nullptr, *m_sumsq = nullptr, *m_scale = nullptr;
-    half_t *m_y = nullptr, *m_h = nullptr;   // split-precision GEMM operands [hi | lo | hi]
+    half_t *m_y = nullptr, *m_h = nullptr;   // split-precision GEMM operands [hi | lo]
     float* m_h32 = nullptr;
     // soft-erosion scratch (allocated on first use for the largest B*H*W seen)
     float *se_a = nullptr, *se_b = nullptr, *se_part = nullptr; size_t se_cap = 0;
@@ -214,6 +214,7 @@ struct ConvCall {
     int cfg = -1, mode = MODE_STD;
     int hcfg = -1;            // forced conv_halo configuration (else derived from Cout_pad)
     int stat_nblk = 0;        // set by go(): partial blocks per sample when p.stat_out is used
+    bool cg_ck64 = false;     // grouped input channels (ConvParams::cg) on 64-channel chunks where the kernel allows it (1x1 convs, even cg)
     double macs_per_pos = 0;
     const char* name = "";
 };
@@ -367,7 +368,11 @@ int go(cs_engine* e, ConvCall& c, hipStream_t st, int prefW = 0, int prefH = 0)
         }
         // SPADE convs run 32-channel chunks: their LDS image is then conflict-free at three workgroups per CU (conv_halo_kernel.h, halo_pad)
         const bool spade_ck32 = c.mode == MODE_SPADE && c.p.Cout_pad % 256 != 0;
-        const int ck = (!is3d && c.p.Cin % 64 == 0 && c.p.cg == 0 && !spade_ck32) ? 64 : 32;
+        // (grouped input channels, ConvParams::cg: 32-channel chunks, except the 1x1 convs that ask for 64 - M's linear layers: a chunk's two
+        // halves lie side by side when cg is even; F's [W_hi | W_lo] convs keep their 32-channel chunks and with them their K order)
+        const bool k11 = c.p.KD == 1 && c.p.KH == 1 && c.p.KW == 1;
+        const bool cg64 = c.cg_ck64 && k11 && c.p.cg > 0 && !(c.p.cg & 1) && c.p.Cin % 64 == 0 && c.mode == MODE_STD;
+        const int ck = (!is3d && c.p.Cin % 64 == 0 && (c.p.cg == 0 || cg64) && !spade_ck32) ? 64 : 32;
         c.p.xcd_map = XCD_MAP;
         c.p.persist_total = HALO_PERSIST;
         {   // cross-workgroup split-K when the launch cannot fill the chip (single-frame latency: the deep hourglass levels run 8-64
@@ -1020,12 +1025,20 @@ int check(cs_engine* e, int B)
 
 // ------------------------------------------------------------------------------------------------ M
 // MotionExtractor.forward (motion_extractor.py:33-35 -> convnextv2.py:110-144): img fp32 NCHW 256x256 -> raw head outputs [B][328]
+// M's split-precision GEMMs: the activations are stored once as [hi | lo] (2 x creal channels per position) and read as the 3 x creal-channel
+// input [hi | lo | hi] the packed weights [W_hi | W_hi | W_lo] expect: chunk j of the conv fetches channels (j mod 2 creal / 32) * 32
+static void msplit_in(ConvCall& c, int creal)
+{
+    c.p.cg = 2 * creal / 32; c.p.cg_cin = 2 * creal; c.p.in_sG = 0;
+    c.cg_ck64 = true;
+}
+
 int run_M(cs_engine* e, int B, const float* img, float* out, hipStream_t st)
 {
     if (!e->has_m) { cs_set_error("the motion extractor weights (M.*) were not uploaded"); return -1; }
     if (!e->m_x) {   // workspace on first use
         const size_t P0 = (size_t)e->maxB * 64 * 64;
-        if (e->alloc(&e->m_x, P0 * 96) || e->alloc(&e->m_y, P0 * 96 * 3) || e->alloc(&e->m_h, P0 * 384 * 3) || e->alloc(&e->m_h32, P0 * 384) ||
+        if (e->alloc(&e->m_x, P0 * 96) || e->alloc(&e->m_y, P0 * 96 * 2) || e->alloc(&e->m_h, P0 * 384 * 2) || e->alloc(&e->m_h32, P0 * 384) ||
             e->alloc(&e->m_sumsq, (size_t)e->maxB * 3072 * 16) || e->alloc(&e->m_scale, (size_t)e->maxB * 3072)) return -1;
     }
     TRY(e->run(1, st, [&] { return launch_m_stem(img, e->m_stem_w, e->m_stem_b, e->m_stem_g, e->m_stem_be, e->m_x, B, 256, 256, st); }, "m_stem"));
@@ -1036,11 +1049,13 @@ int run_M(cs_engine* e, int B, const float* img, float* out, hipStream_t st)
         for (int j = 0; j < S.n; ++j) {
             const cs_engine::MBlk& K = S.blk[j];
             TRY(e->run(1, st, [&] { return launch_m_dwln(e->m_x, K.dw_w, K.dw_b, K.ln_g, K.ln_b, e->m_y, B, H, H, C, st); }, "m_dwln"));
-            ConvCall a = mk(K.pw1, e->m_y, nhwc(nullptr, H, H, 3 * C), B, 1, H, H);              // convnextv2.py:39-40
+            ConvCall a = mk(K.pw1, e->m_y, nhwc(nullptr, H, H, 2 * C), B, 1, H, H);              // convnextv2.py:39-40
+            msplit_in(a, C);
             a.p.act0 = ACT_GELU; a.p.out0 = nhwc(e->m_h32, H, H, 4 * C); a.p.out0_f32 = 1;
             TRY(go(e, a, st));
             TRY(e->run(1, st, [&] { return launch_m_grn(e->m_h32, K.grn_g, K.grn_b, e->m_sumsq, e->m_scale, e->m_h, B, H * H, 4 * C, st); }, "m_grn"));
-            ConvCall b = mk(K.pw2, e->m_h, nhwc(nullptr, H, H, 12 * C), B, 1, H, H);             // :42 + residual :45
+            ConvCall b = mk(K.pw2, e->m_h, nhwc(nullptr, H, H, 8 * C), B, 1, H, H);              // :42 + residual :45
+            msplit_in(b, 4 * C);
             b.p.res = nhwc(e->m_x, H, H, C); b.p.res_f32 = 1;
             b.p.out0 = nhwc(e->m_x, H, H, C); b.p.out0_f32 = 1;
             TRY(go(e, b, st));
@@ -1048,7 +1063,8 @@ int run_M(cs_engine* e, int B, const float* img, float* out, hipStream_t st)
         if (i < 3) {   // downsample_layers[i+1]: LayerNorm + Conv2d(k=2, s=2) as space-to-depth + 1x1 conv
             TRY(e->run(1, st, [&] { return launch_m_ln_s2d(e->m_x, S.ds_g, S.ds_b, e->m_y, B, H, H, C, st); }, "m_ln_s2d"));
             H /= 2;
-            ConvCall d = mk(S.ds, e->m_y, nhwc(nullptr, H, H, 12 * C), B, 1, H, H);
+            ConvCall d = mk(S.ds, e->m_y, nhwc(nullptr, H, H, 8 * C), B, 1, H, H);
+            msplit_in(d, 4 * C);
             d.p.out0 = nhwc(e->m_x, H, H, 2 * C); d.p.out0_f32 = 1;
             TRY(go(e, d, st));
         }

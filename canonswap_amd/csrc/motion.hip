@@ -9,18 +9,20 @@
 //
 // Precision: the key-points steer the generator's warps, and with fp16 GEMM operands M's outputs are only good to 1e-3
 // (41 dB on the generated frame).  M is 0.5 % of the frame's FLOPs, so its GEMMs run in split precision on the same fp16
-// MFMA kernel: an activation row of C' values is stored as the 3C' fp16 vector [hi | lo | hi] (hi = fp16(v), lo =
-// fp16(v - hi)) and the weights are packed as [W_hi | W_hi | W_lo] along the input-channel axis (pack._pack_M), so one
-// conv computes W_hi v_hi + W_hi v_lo + W_lo v_hi with fp32 accumulation (the dropped W_lo v_lo term is 2^-22 relative).
+// MFMA kernel: the weights are packed as [W_hi | W_hi | W_lo] along the input-channel axis (pack._pack_M) and an activation row
+// of C' values is stored as the 2C' fp16 vector [hi | lo] (hi = fp16(v), lo = fp16(v - hi)), which the conv reads as the 3C'-channel
+// input [hi | lo | hi]: its 32-channel chunk j fetches channels (j mod 2C'/32) * 32 (ConvParams::cg at group stride 0, the addressing
+// F's [W_hi | W_lo] convs use) - round 6; before, the third copy was stored and fetched (a third of the operand bytes of a memory-bound
+// network).  One conv computes W_hi v_hi + W_hi v_lo + W_lo v_hi with fp32 accumulation (the dropped W_lo v_lo term is 2^-22 relative).
 #include "common.h"
 
 namespace {
 
-// store v as the split-precision triple [hi | lo | hi] at channel c of a row of C values (row stride 3C)
+// store v as the split-precision pair [hi | lo] at channel c of a row of C values (row stride 2C)
 __device__ __forceinline__ void store_split(half_t* row, int C, int c, float v)
 {
     const half_t hi = (half_t)v;
-    row[c] = hi; row[C + c] = (half_t)(v - (float)hi); row[2 * C + c] = hi;
+    row[c] = hi; row[C + c] = (half_t)(v - (float)hi);
 }
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256) m_stem_kernel(const float* __restrict__ i
     }
 }
 
-// Block front half: depth-wise 7x7 conv (padding 3) + LayerNorm (convnextv2.py:36-38); x fp32 -> y split fp16 [N][H][W][3C].
+// Block front half: depth-wise 7x7 conv (padding 3) + LayerNorm (convnextv2.py:36-38); x fp32 -> y split fp16 [N][H][W][2C].
 // wt: [49][C] (tap-major so lanes read consecutive channels).  One wavefront owns a run of DWP consecutive positions of a row:
 // every input element of the 7 x (DWP+6) window is loaded once and scattered into the outputs it feeds (4x fewer loads than
 // a window per position), the 7 weights of the current kernel row sit in registers.
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(256) m_dwln_kernel(const float* __restrict__ x
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = acc[p][k];
         wave_layernorm<K>(v, C, lane, 1e-6f);
-        half_t* o = y + ((((long)n * H + h0) * W) + w0 + p) * 3 * C;
+        half_t* o = y + ((((long)n * H + h0) * W) + w0 + p) * 2 * C;
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (lane + 64 * k < C) store_split(o, C, lane + 64 * k, v[k] * g[lane + 64 * k] + be[lane + 64 * k]);
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(256) m_dwln_kernel(const float* __restrict__ x
 }
 
 // Downsample front half: LayerNorm(channels_first) + space-to-depth for the 2x2 stride-2 conv (convnextv2.py:70-75):
-// x fp32 [N][H][W][C] -> y split fp16 [N][H/2][W/2][3 x 4C], inner index (dy*2+dx)*C + c.
+// x fp32 [N][H][W][C] -> y split fp16 [N][H/2][W/2][2 x 4C], inner index (dy*2+dx)*C + c.
 template <int K>
 __global__ void __launch_bounds__(256) m_ln_s2d_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
                                                        half_t* __restrict__ y, int N, int H, int W, int C)
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(256) m_ln_s2d_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = (lane + 64 * k < C) ? xr[lane + 64 * k] : 0.f;
     wave_layernorm<K>(v, C, lane, 1e-6f);
-    half_t* o = y + (((long)n * (H / 2) + (h0 >> 1)) * (W / 2) + (w0 >> 1)) * 12 * C;
+    half_t* o = y + (((long)n * (H / 2) + (h0 >> 1)) * (W / 2) + (w0 >> 1)) * 8 * C;
     const int sub = ((h0 & 1) * 2 + (w0 & 1)) * C;
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(256) m_grn_scale_kernel(const float* __restric
     for (int c = threadIdx.x; c < C; c += 256) scale[(long)n * C + c] = 1.f + gamma[c] * gx[c] * inv;
 }
 
-// out[pos] = split(h * scale[n][c] + beta[c]): fp32 [N][P][C] -> split fp16 [N][P][3C], 4 channels per thread
+// out[pos] = split(h * scale[n][c] + beta[c]): fp32 [N][P][C] -> split fp16 [N][P][2C], 4 channels per thread
 __global__ void __launch_bounds__(256) m_grn_apply_kernel(const float* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ beta,
                                                           half_t* __restrict__ out, long per_n, int C, long total4)
 {
@@ -303,8 +305,8 @@ __global__ void __launch_bounds__(256) m_grn_apply_kernel(const float* __restric
         const float a = v[r] * scale[(long)n * C + c + r] + beta[c + r];
         hi[r] = (half_t)a; lo[r] = (half_t)(a - (float)hi[r]);
     }
-    half_t* o = out + pos * 3 * C + c;
-    *(h4_t*)o = hi; *(h4_t*)(o + C) = lo; *(h4_t*)(o + 2 * C) = hi;
+    half_t* o = out + pos * 2 * C + c;
+    *(h4_t*)o = hi; *(h4_t*)(o + C) = lo;
 }
 
 // Global average pool + final LayerNorm + the 7 linear heads (convnextv2.py:114-131). x fp32 [N][P][768] -> out fp32 [N][328]
