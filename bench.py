@@ -373,6 +373,25 @@ def main():
             chain_step()
         torch.cuda.synchronize(dev)
         cdt = time.perf_counter() - t0
+        # ... and with stage A (staging, M, key-points, soft masks) of batch k + 1 on a side stream beside the generator of batch k - the
+        # reference runs that stage as a pre-pass over the whole video (can_swap_pipeline_e2e.py:196-197), so nothing of frame k + 1 depends on frame k
+        crops_b = crops.clone()                              # the "next" batch is another tensor object: FrameChain matches a prefetch by identity
+
+        def pipe_run(n):
+            cur, nxt = crops, crops_b
+            fc.prefetch(cur, masks)
+            for _ in range(n):
+                fc.prefetch(nxt, masks)                      # batch k + 1 is queued on the side stream before the launches of batch k
+                fc(cur, masks, Ms, ori, slots=slots0, out=outf)
+                cur, nxt = nxt, cur
+            fc.drop_prefetches()
+        pipe_run(2)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pipe_run(K)
+        torch.cuda.synchronize(dev)
+        pdt = time.perf_counter() - t0
+        del crops_b
         I_c, xt_c, xc_c = r0["I"], r0["x_t"].clone(), r0["x_can"].clone()
         gen_u8 = torch.empty(B, 512, 512, 3, dtype=torch.uint8, device=dev)
 
@@ -413,6 +432,8 @@ def main():
                              "uint8 frames (can_swap_pipeline_e2e.py:111-125, 196, 242-283 without its host round trips)",
                  "frames": K * B, "value": round(K * B / cdt, 3), "unit": "frames/s", "ms_per_step": round(cdt / K * 1e3, 3),
                  "generator_alone_same_keypoints": round(K * B / gdt, 3), "ratio_to_generator": round(gdt / cdt, 4),
+                 "value_overlapped": round(K * B / pdt, 3), "ratio_to_generator_overlapped": round(gdt / pdt, 4),
+                 "overlapped": "staging + M + key-points + soft masks of batch k + 1 on a side HIP stream beside the generator of batch k (FrameChain.prefetch)",
                  "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
                  "stage_rates": {"prepare_crops_GBps": round(stage_bytes["prepare_crops"] * B / max(stage_ms["prepare_crops"], 1e-9) / 1e6, 1),
                                  "soft_erosion_GBps": round(stage_bytes["soft_erosion"] * B / max(stage_ms["soft_erosion"], 1e-9) / 1e6, 1),

@@ -231,13 +231,13 @@ class Engine:
             o += n
         return res
 
-    def motion_keypoints(self, raw, want_rot=False):
+    def motion_keypoints(self, raw, want_rot=False, out=None):
         """Key-points from motion_extract's raw head outputs (B, 328), on the device: get_kp_info's refinement + get_rotation_matrix +
         transform_keypoint (can_swap_e2e.py:192-197, 228-256; camera.py:14-73) -> x_t (B,21,3), x_can = scale * kp (B,21,3)
         (can_swap_pipeline_e2e.py:243)[, R (B,3,3)]."""
         raw = self._in(raw, (328,))
         B = raw.shape[0]
-        x_t, x_can = self._new(B, 21, 3), self._new(B, 21, 3)
+        x_t, x_can = (self._out(o, (B, 21, 3), torch.float32) for o in (out if out is not None else (None, None)))
         rot = self._new(B, 3, 3) if want_rot else None
         _lib.check(self.lib.cs_motion_keypoints(self.h, B, _ptr(raw), _ptr(x_t), _ptr(x_can), _ptr(rot), self._stream()), "cs_motion_keypoints")
         return (x_t, x_can, rot) if want_rot else (x_t, x_can)

@@ -165,7 +165,7 @@ def paste_back_fused(e: Engine, img_crop, mask_crop, M_c2o, img_ori):
     return out
 
 
-def prepare_crops(e: Engine, crops_u8) -> torch.Tensor:
+def prepare_crops(e: Engine, crops_u8, out=None) -> torch.Tensor:
     """uint8 crops (B,512,512,3) or (B,256,256,3), host or device -> (B,3,256,256) fp32 in [0,1] on the device: the cropper's
     cv2.resize(..., (256, 256), INTER_AREA) (cropper.py:209) fused with prepare_source / prepare_videos (can_swap_e2e.py:126-163)."""
     t = torch.as_tensor(crops_u8)
@@ -175,7 +175,10 @@ def prepare_crops(e: Engine, crops_u8) -> torch.Tensor:
         raise ValueError("expected BxHxWx3 uint8 crops")
     t = t.to(e.device).contiguous()
     B, H, W, _ = t.shape
-    out = torch.empty((B, 3, 256, 256), dtype=torch.float32, device=e.device)
+    if out is None:
+        out = torch.empty((B, 3, 256, 256), dtype=torch.float32, device=e.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (B, 3, 256, 256) or not out.is_contiguous() or out.device != e.device:
+        raise ValueError("out must be a contiguous (B, 3, 256, 256) fp32 tensor on the engine's device")
     with torch.cuda.device(e.device):
         _lib.check(e.lib.cs_prepare_crops(e.h, B, _ptr(t), H, W, _ptr(out), e._stream()), "cs_prepare_crops")
     return out

@@ -177,3 +177,36 @@ def test_chain_vs_oracle_loop(swapper_m, sds_m):
         worst = min(worst, p)
         assert np.abs(d).mean() < 0.6
     assert worst >= 48.0                                                           # uint8 frames: the gate of the generator's u8 output
+
+
+def test_prefetched_stage_a_gives_the_same_frames(swapper_m):
+    """FrameChain.prefetch: staging + M + key-points + soft masks of the next batch on a side stream (double-buffered) beside the current batch's
+    generator - the same bytes as the in-line chain, batch after batch."""
+    from canonswap_amd import synth
+    from canonswap_amd.chain import FrameChain
+    B, Ho, Wo = 2, 360, 640
+    r = np.random.Generator(np.random.PCG64(29))
+    idv = torch.from_numpy(synth.make_identity(7)).cuda()
+    batches = []
+    for k in range(3):
+        smooth = synth.make_smooth_images(B, seed=2200 + k, size=512)
+        crops = torch.from_numpy(np.ascontiguousarray((smooth.transpose(0, 2, 3, 1) * 255).astype(np.uint8))).cuda()
+        masks = torch.from_numpy(_masks(B, seed=31 + k)).cuda()
+        ori = torch.from_numpy(r.integers(0, 256, size=(B, Ho, Wo, 3), dtype=np.uint8)).cuda()
+        Ms = np.stack([_affine(j, Ho, Wo) * np.array([[0.4], [0.4], [1]]) + np.array([[0, 0, 60.], [0, 0, 10.], [0, 0, 0]]) for j in range(B)])
+        batches.append((crops, masks, Ms, ori))
+    chain = FrameChain(swapper_m)
+    want = [chain(c, m, M, o, idv)["frames"].clone() for c, m, M, o in batches]
+    chain.prefetch(batches[0][0], batches[0][1])
+    got = []
+    for k, (c, m, M, o) in enumerate(batches):
+        if k + 1 < len(batches):
+            chain.prefetch(batches[k + 1][0], batches[k + 1][1])
+        got.append(chain(c, m, M, o, idv)["frames"].clone())
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert torch.equal(got[k], want[k]), k
+    assert not torch.equal(want[0], want[1])
+    with pytest.raises(RuntimeError):
+        chain.prefetch(batches[0][0], batches[0][1]); chain.prefetch(batches[1][0], batches[1][1]); chain.prefetch(batches[2][0], batches[2][1])
+    chain.drop_prefetches()
