@@ -203,15 +203,18 @@ const half_t* cs_zero_page();   // per-process device buffer of zeros (lazily al
 int launch_conv_first(const float* img, const float* w, const float* b, half_t* out, int N, int H, int W, hipStream_t st);
 int launch_avgpool(const half_t* in, int N, int D, int H, int W, int C, TDesc out, hipStream_t st);
 int launch_dm_compress(const float* f, const float* w, const float* b, half_t* comp, int N, int D, int H, int W, hipStream_t st);
+// shared_*: one compressed / feature volume, one kp_s set for all N samples (sample stride 0: the v2i body warps ONE swapped canonical volume)
 int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, half_t* out, int out_stride, int N, int D,
-                     int H, int W, hipStream_t st);
+                     int H, int W, hipStream_t st, bool shared_comp = false, bool shared_kps = false);
 int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
-                      int N, int D, int H, int W, hipStream_t st, int compact = 0);
+                      int N, int D, int H, int W, hipStream_t st, int compact = 0, bool shared_kps = false);
 int launch_dm_softmax_warp(const float* part, const float* bias, const float* kp_d, const float* kp_s, const float* in, float* out32,
-                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact = 0);
+                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact = 0, bool shared_in = false,
+                           bool shared_kps = false);
 int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
 int launch_occ_finish49(const float* part, float bias, float* occ, int N, int H, int W, hipStream_t st);
-int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st);
+int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st,
+                       bool shared_in = false);
 int launch_chan_stats(const void* x, int is_f32, int N, long P, int C, float eps, float* partials, float* stats, hipStream_t st);
 long chan_stats_partial_floats(int N, long P, int C);
 int launch_chan_stats_finish(const float* partials, int nblk, int N, int C, double cnt_inv, float eps, float* stats, hipStream_t st);

@@ -549,12 +549,15 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 bool warp_fused() { static const bool on = [] { const char* s = getenv("CANONSWAP_WARP_FUSED"); return !s || atoi(s) != 0; }(); return on; }
 
 int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st,
-                     const float* warp_in = nullptr, float* warp_o32 = nullptr, half_t* warp_o16 = nullptr, bool want_deform = false)
+                     const float* warp_in = nullptr, float* warp_o32 = nullptr, half_t* warp_o16 = nullptr, bool want_deform = false,
+                     bool shared_feat = false, bool shared_kps = false)
 {
-    TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, B, FD, FH, FW, st); }, "dm_compress"));
+    // shared_feat / shared_kps: `feat` (and warp_in) is ONE volume, kp_s ONE key-point set, used by all B samples (sample stride 0 in the kernels
+    // that read them; the compressed volume is computed once) - the v2i body (can_swap_pipeline_v2i.py:311-312)
+    TRY(e->run(1, st, [&] { return launch_dm_compress(feat, e->cmp_w, e->cmp_b, e->dm_comp, shared_feat ? 1 : B, FD, FH, FW, st); }, "dm_compress"));
     e->flops += 2.0 * 32 * 4 * VOX * B;
     // hourglass input lands in channels [32,144) of the level-0 concat buffer (util.py:255-264 cat order)
-    TRY(e->run(1, st, [&] { return launch_dm_sparse(e->dm_comp, kp_d, kp_s, e->dm_l[0] + 32, 144, B, FD, FH, FW, st); }, "dm_sparse"));
+    TRY(e->run(1, st, [&] { return launch_dm_sparse(e->dm_comp, kp_d, kp_s, e->dm_l[0] + 32, 144, B, FD, FH, FW, st, shared_feat, shared_kps); }, "dm_sparse"));
     static const int cin[5] = {112, 64, 128, 256, 512}, cout[5] = {64, 128, 256, 512, 1024};
     static const int lw[6] = {144, 128, 256, 512, 1024, 1024};   // concat widths per level
     static const int skip_off[6] = {32, 64, 128, 256, 512, 0};   // channel offset of the skip part
@@ -635,11 +638,11 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
     m.hcfg = CFG_H_256x160;
     TRY(go(e, m, st, compact == 2 ? 4 : 2, 8));     // no halo along W (KW = 1)
     if (warp_in && !mask_out && warp_fused()) {
-        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, want_deform ? e->dm_deform : nullptr, B, FD, FH, FW, st, compact); },
+        TRY(e->run(2, st, [&] { return launch_dm_softmax_warp(e->dm_logits, e->mask_b, kp_d, kp_s, warp_in, warp_o32, warp_o16, want_deform ? e->dm_deform : nullptr, B, FD, FH, FW, st, compact, shared_feat, shared_kps); },
                    "dm_softmax_warp"));
     } else {
-        TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st, compact); }, "dm_softmax"));
-        if (warp_in) TRY(e->run(2, st, [&] { return launch_grid_sample(warp_in, e->dm_deform, warp_o32, warp_o16, B, FD, FH, FW, st); }, "grid_sample"));
+        TRY(e->run(1, st, [&] { return launch_dm_softmax(e->dm_logits, e->mask_b, kp_d, kp_s, e->dm_deform, mask_out, B, FD, FH, FW, st, compact, shared_kps); }, "dm_softmax"));
+        if (warp_in) TRY(e->run(2, st, [&] { return launch_grid_sample(warp_in, e->dm_deform, warp_o32, warp_o16, B, FD, FH, FW, st, shared_feat); }, "grid_sample"));
     }
     // occlusion (dense_motion.py:98-102): the (c,d)-flattened 2272-channel 7x7 conv runs as a 2-D (7,1)-tap conv whose
     // input channels are grouped by depth slice (16 groups of 144 channels at stride sD) and whose 7 output channels are the
@@ -1538,13 +1541,9 @@ extern "C" int cs_animate_frames(cs_engine* e, int B, const float* f, int nf, co
     if ((nf != 1 && nf != B) || (ns != 1 && ns != B)) { cs_set_error("cs_animate_frames: nf / ns must be 1 or B"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     TRY(to_hwdc(e, nf, f, e->vs[0], nullptr, st));
-    for (int b = nf; b < B; ++b) TRY(copy_dd(e->vs[0] + (size_t)b * VOL, e->vs[0], (size_t)VOL * 4, st));
-    const float* ks = kp_source;
-    if (ns == 1 && B > 1) {
-        for (int b = 0; b < B; ++b) TRY(copy_dd(e->kpbuf + (size_t)b * 63, kp_source, 63 * 4, st));
-        ks = e->kpbuf;
-    }
-    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, ks, nullptr, st, e->vs[0], nullptr, e->va[0]));      // dense motion + the feature warp it drives
+    // nf == 1 / ns == 1: the one volume / key-point set is broadcast by a zero sample stride in the kernels that read it (round 6; before: B - 1
+    // device copies of 8.4 MB and B of 252 bytes per call)
+    TRY(run_dense_motion(e, B, e->vs[0], kp_driving, kp_source, nullptr, st, e->vs[0], nullptr, e->va[0], false, nf == 1 && B > 1, ns == 1 && B > 1));
     TRY(run_warp_out(e, B, e->va[0], e->dm_occ, st));
     float* dst = out_f32 ? out_f32 : e->img_a;
     TRY(run_G(e, B, e->seg16, dst, st));

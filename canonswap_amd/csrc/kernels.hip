@@ -161,8 +161,10 @@ __device__ __forceinline__ float grid_coord(int i, int n) { return 2.f * ((float
 // a voxel are assembled in an LDS row image and leave as 16-byte stores.
 __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict__ comp, const float* __restrict__ kp_d,
                                                         const float* __restrict__ kp_s, half_t* __restrict__ out, int ostride,
-                                                        int N, int D, int H, int W)
+                                                        int N, int D, int H, int W, long comp_sN, int kps_sN)
 {
+    // comp_sN / kps_sN: sample strides of the compressed volume and of kp_s (0: one volume / one key-point set shared by all samples - the
+    // v2i body, can_swap_pipeline_v2i.py:311-312)
     constexpr int RS = 120;                                  // LDS row stride in halfs (112 used; 240 bytes: 16-byte aligned rows)
     __shared__ __attribute__((aligned(16))) half_t tile[64 * RS];
     const int t = threadIdx.x, x = t & 63;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
     const int n = r / D;
     const long v0 = (((long)n * D + d) * H + y) * W;         // first voxel of the row
     const float gx = grid_coord(x, W), gy = grid_coord(y, H), gz = grid_coord(d, D);
-    const half_t* base = comp + (long)n * D * H * W * 4;
+    const half_t* base = comp + (long)n * comp_sN;
     for (int k = t >> 6; k < 23; k += 4) {                   // wave-uniform slot
         if (x >= W) continue;
         half_t* o = tile + x * RS + k * 5;
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
         float sx = gx, sy = gy, sz = gz, heat = 0.f;
         if (k > 0) {
             const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
-            const float* ps = kp_s + ((long)n * 21 + (k - 1)) * 3;
+            const float* ps = kp_s + (long)n * kps_sN + (k - 1) * 3;
             sx = (gx - pd[0]) + ps[0]; sy = (gy - pd[1]) + ps[1]; sz = (gz - pd[2]) + ps[2];
             const float dd = (gx - pd[0]) * (gx - pd[0]) + (gy - pd[1]) * (gy - pd[1]) + (gz - pd[2]) * (gz - pd[2]);
             const float ds = (gx - ps[0]) * (gx - ps[0]) + (gy - ps[1]) * (gy - ps[1]) + (gz - ps[2]) * (gz - ps[2]);
@@ -236,11 +238,12 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
 }
 
 int launch_dm_sparse(const half_t* comp, const float* kp_d, const float* kp_s, half_t* out, int out_stride, int N, int D, int H,
-                     int W, hipStream_t st)
+                     int W, hipStream_t st, bool shared_comp, bool shared_kps)
 {
     if (((uintptr_t)out & 15) || (out_stride & 7)) { cs_set_error("dm_sparse: output rows must be 16-byte aligned"); return -1; }
     if (W > 64) { cs_set_error("dm_sparse: rows of at most 64 voxels"); return -1; }
-    hipLaunchKernelGGL(dm_sparse_kernel, dim3((unsigned)((long)N * D * H)), dim3(256), 0, st, comp, kp_d, kp_s, out, out_stride, N, D, H, W);
+    hipLaunchKernelGGL(dm_sparse_kernel, dim3((unsigned)((long)N * D * H)), dim3(256), 0, st, comp, kp_d, kp_s, out, out_stride, N, D, H, W,
+                       shared_comp ? 0L : (long)D * H * W * 4, shared_kps ? 0 : 63);
     LAUNCH_CHECK("dm_sparse");
     return 0;
 }
@@ -303,7 +306,7 @@ __device__ __forceinline__ void dm_logits(float (&l)[22], const float* __restric
 __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                          const float* __restrict__ kp_d, const float* __restrict__ kp_s,
                                                          float* __restrict__ deform, float* __restrict__ mask_out, int N, int D, int H, int W,
-                                                         int compact)
+                                                         int compact, int kps_sN)
 {
     const long total = (long)N * D * H * W;
     const long v = (long)blockIdx.x * 256 + threadIdx.x;
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
 #pragma unroll
     for (int k = 1; k < 22; ++k) {
         const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
-        const float* ps = kp_s + ((long)n * 21 + (k - 1)) * 3;
+        const float* ps = kp_s + (long)n * kps_sN + (k - 1) * 3;
         const float m = l[k] * inv;
         ox = fmaf(m, (gx - pd[0]) + ps[0], ox);
         oy = fmaf(m, (gy - pd[1]) + ps[1], oy);
@@ -342,11 +345,11 @@ __global__ void __launch_bounds__(256) dm_softmax_kernel(const float* __restrict
 }
 
 int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, const float* kp_s, float* deform, float* mask_out,
-                      int N, int D, int H, int W, hipStream_t st, int compact)
+                      int N, int D, int H, int W, hipStream_t st, int compact, bool shared_kps)
 {
     if ((compact == 1 && (W & 1)) || (compact == 2 && (W & 3))) { cs_set_error("dm_softmax: the compact partial layouts need a width that is a multiple of the tile's columns"); return -1; }
     hipLaunchKernelGGL(dm_softmax_kernel, dim3(cdiv((long)N * D * H * W, 256)), dim3(256), 0, st, part, bias, kp_d, kp_s,
-                       deform, mask_out, N, D, H, W, compact);
+                       deform, mask_out, N, D, H, W, compact, shared_kps ? 0 : 63);
     LAUNCH_CHECK("dm_softmax");
     return 0;
 }
@@ -360,7 +363,8 @@ int launch_dm_softmax(const float* part, const float* bias, const float* kp_d, c
 __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                               const float* __restrict__ kp_d, const float* __restrict__ kp_s,
                                                               const float* __restrict__ in, float* __restrict__ out32, half_t* __restrict__ out16,
-                                                              float* __restrict__ deform, int N, int D, int H, int W, int compact)
+                                                              float* __restrict__ deform, int N, int D, int H, int W, int compact,
+                                                              long in_sN, int kps_sN)
 {
     __shared__ float defs[256 * 3];
     long blk = blockIdx.x;
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
 #pragma unroll
         for (int k = 1; k < 22; ++k) {
             const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
-            const float* ps = kp_s + ((long)n * 21 + (k - 1)) * 3;
+            const float* ps = kp_s + (long)n * kps_sN + (k - 1) * 3;
             const float m = l[k] * inv;
             ox = fmaf(m, (gx - pd[0]) + ps[0], ox);
             oy = fmaf(m, (gy - pd[1]) + ps[1], oy);
@@ -399,7 +403,7 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
     __syncthreads();
     // ---- phase 2: trilinear gather (grid_sample_kernel's arithmetic), voxel j = (w, d) = (j >> 4, j & 15) -> 8 lanes x float4
     const int cg = t & 7;
-    const float* base = in + (long)n * H * W * D * 32 + cg * 4;
+    const float* base = in + (long)n * in_sN + cg * 4;         // in_sN = 0: every sample warps the one shared volume (v2i)
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const int j = it * 32 + (t >> 3), wl = j >> 4, d = j & 15;
@@ -439,11 +443,11 @@ __global__ void __launch_bounds__(256) dm_softmax_warp_kernel(const float* __res
 }
 
 int launch_dm_softmax_warp(const float* part, const float* bias, const float* kp_d, const float* kp_s, const float* in, float* out32,
-                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact)
+                           half_t* out16, float* deform, int N, int D, int H, int W, hipStream_t st, int compact, bool shared_in, bool shared_kps)
 {
     if (D != 16 || (W & 15)) { cs_set_error("dm_softmax_warp: depth 16 and a width that is a multiple of 16"); return -1; }
     hipLaunchKernelGGL(dm_softmax_warp_kernel, dim3((unsigned)((long)N * H * (W >> 4))), dim3(256), 0, st, part, bias, kp_d, kp_s, in,
-                       out32, out16, deform, N, D, H, W, compact);
+                       out32, out16, deform, N, D, H, W, compact, shared_in ? 0L : (long)H * W * D * 32, shared_kps ? 0 : 63);
     LAUNCH_CHECK("dm_softmax_warp");
     return 0;
 }
@@ -509,7 +513,7 @@ int launch_occ_finish(const float* part, float bias, float* occ, int N, int H, i
 // 32 channels with float4 accesses, so every tap is one 128-byte coalesced read.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restrict__ in, const float* __restrict__ grid,
-                                                          float* __restrict__ out32, half_t* __restrict__ out16, int N, int D, int H, int W)
+                                                          float* __restrict__ out32, half_t* __restrict__ out16, int N, int D, int H, int W, long in_sN)
 {
     const long total = (long)N * H * W * D * 8;
     // XCD-aware block order: hardware places workgroup b on XCD b % 8 (each with its own L2); every XCD walks a contiguous eighth of the
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restric
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
     const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* base = in + (long)n * H * W * D * 32 + cg * 4;
+    const float* base = in + (long)n * in_sN + cg * 4;
     float4 cv[8]; float wv[8];           // all eight corners fetched back to back (see dm_sparse_kernel)
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
@@ -557,9 +561,10 @@ __global__ void __launch_bounds__(256) grid_sample_kernel(const float* __restric
     }
 }
 
-int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st)
+int launch_grid_sample(const float* in, const float* grid, float* out32, half_t* out16, int N, int D, int H, int W, hipStream_t st, bool shared_in)
 {
-    hipLaunchKernelGGL(grid_sample_kernel, dim3(cdiv((long)N * D * H * W * 8, 256)), dim3(256), 0, st, in, grid, out32, out16, N, D, H, W);
+    hipLaunchKernelGGL(grid_sample_kernel, dim3(cdiv((long)N * D * H * W * 8, 256)), dim3(256), 0, st, in, grid, out32, out16, N, D, H, W,
+                       shared_in ? 0L : (long)H * W * D * 32);
     LAUNCH_CHECK("grid_sample");
     return 0;
 }

@@ -196,6 +196,9 @@ def test_animate_frames_v2i(swapper, case, state_dicts):
     assert O.psnr(got["out"].cpu(), want) >= PSNR_GATE
     stage = swapper.warp_decode(f.expand(2, -1, -1, -1, -1).contiguous().cuda(), ks.expand(2, -1, -1).contiguous().cuda(), kd.cuda())["out"]
     assert O.psnr(got["out"].cpu(), stage.cpu()) > 60.0
+    # the shared volume / key-point set is broadcast by a zero sample stride inside the kernels (round 6): the same bits as B copies of it
+    rep = swapper.animate_frames(f.expand(2, -1, -1, -1, -1).contiguous().cuda(), ks.expand(2, -1, -1).contiguous().cuda(), kd.cuda(), want_u8=True)
+    assert torch.equal(rep["out"], got["out"]) and torch.equal(rep["out_u8"], got["out_u8"])
     with pytest.raises(ValueError):
         swapper.animate_frames(ref["f_ref"][:2].repeat(2, 1, 1, 1, 1)[:3].cuda(), ks.cuda(), kd.cuda())
 
