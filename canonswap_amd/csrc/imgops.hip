@@ -23,7 +23,7 @@
 // Round 6: register tiled.  A workgroup owns 64 x 32 outputs, a thread 8 consecutive outputs of one row: per kernel row it reads the
 // 8 + KS - 1 inputs it needs ONCE from LDS (seven ds_read_b128; the lane -> address map (row stride 84 floats, 32 B between lanes) is
 // conflict free for that instruction: the 16 lanes of a group cover the 64 banks) and issues KS x 8 FMAs on them, the weights are
-// wave-uniform scalar loads.  One LDS read per six FMAs instead of two per FMA: the pass is VALU-bound (0.69 GFLOP per frame and
+// wave-uniform scalar loads, the FMAs packed two per instruction (v_pk_fma_f32).  One LDS read per six FMAs instead of two per FMA: the pass is VALU-bound (0.69 GFLOP per frame and
 // three passes, crop.py:29-35 - the kernel is a cone, not separable).  An output's products are added in the order (ky, kx) ascending.
 // IN: float (0/1 masks as the reference's .float() makes them, or the previous pass) or uint8 (0/1 labels straight from the parser).
 template <int KS, typename IN>
@@ -35,29 +35,50 @@ __global__ void __launch_bounds__(256) se_conv_kernel(const IN* __restrict__ in,
     __shared__ __attribute__((aligned(16))) float tile[LH * LW + 4];
     const int n = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const IN* src = in + (long)n * H * W;
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int ly = i / LW, lx = i % LW, y = y0 + ly - R, x = x0 + lx - R;
-        tile[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (float)src[(long)y * W + x] : 0.f;
+    {   // staging: thread -> (column lx, rows ly0, ly0 + 3, ...): one division per thread, not per element (252 of the 256 threads; LW = 84)
+        const int lx = threadIdx.x % LW, ly0 = threadIdx.x / LW, x = x0 + lx - R;
+        const bool xin = (unsigned)x < (unsigned)W;
+        if (ly0 < 3) {
+#pragma unroll 6
+            for (int ly = ly0; ly < LH; ly += 3) {
+                const int y = y0 + ly - R;
+                tile[ly * LW + lx] = (xin && (unsigned)y < (unsigned)H) ? (float)src[(long)y * W + x] : 0.f;
+            }
+        }
     }
     __syncthreads();
     const int g = threadIdx.x & 7, r = threadIdx.x >> 3;
-    float acc[NX];
+    // packed fp32 FMAs (v_pk_fma_f32: two lanes' worth of FMA per instruction slot): outputs in pairs (2p, 2p + 1); an even tap reads the
+    // aligned input pairs E[j] = (v[2j], v[2j + 1]), an odd tap the shifted pairs O[j] = (v[2j + 1], v[2j + 2]) (one v_pk_mov_b32 each per
+    // kernel row).  84 packed FMAs + 13 moves per kernel row instead of 168 FMAs; every output still adds its products in (ky, kx) order.
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    constexpr int NP = NX / 2, NE = NV * 2;
+    f2_t acc2[NP];
 #pragma unroll
-    for (int o = 0; o < NX; ++o) acc[o] = 0.f;
+    for (int p = 0; p < NP; ++p) acc2[p] = (f2_t){0.f, 0.f};
 #pragma unroll 1
     for (int ky = 0; ky < KS; ++ky) {
         const float4* rp = (const float4*)(tile + (r + ky) * LW + g * NX);
-        float v[NV * 4];
+        f2_t E[NE], O[NE - 1];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { const float4 q = rp[j]; v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w; }
+        for (int j = 0; j < NV; ++j) { const float4 q = rp[j]; E[2 * j] = (f2_t){q.x, q.y}; E[2 * j + 1] = (f2_t){q.z, q.w}; }
+#pragma unroll
+        for (int j = 0; j < NE - 1; ++j) O[j] = (f2_t){E[j].y, E[j + 1].x};
         const float* wr = w + ky * KS;
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
             const float wv = wr[kx];
+            const f2_t w2 = (f2_t){wv, wv};
 #pragma unroll
-            for (int o = 0; o < NX; ++o) acc[o] = fmaf(v[o + kx], wv, acc[o]);
+            for (int p = 0; p < NP; ++p) {
+                const f2_t in2 = (kx & 1) ? O[p + (kx - 1) / 2] : E[p + kx / 2];
+                acc2[p] = __builtin_elementwise_fma(in2, w2, acc2[p]);
+            }
         }
     }
+    float acc[NX];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { acc[2 * p] = acc2[p].x; acc[2 * p + 1] = acc2[p].y; }
     const int y = y0 + r, xb = x0 + g * NX;
     if (y >= H) return;
     float res[NX];
