@@ -287,6 +287,9 @@ int pick_halo_cfg(const ConvParams& p, int mode)
         const bool k33 = p.KH == 3 && p.KW == 3, k11 = p.KD == 1 && p.KH == 1 && p.KW == 1 && mode == MODE_STD;
         if ((mode == MODE_STD || mode == MODE_STDSTAT) && (k33 || k11) && tiles * (Cout_pad / 128) <= 128)
             return CFG_H_128x64;
+        // ... and the 1x1 convs up to one workgroup per CU: M's stage-3 pwconv2 and last down-sampling conv are 32 x 6 = 192 workgroups of 288 /
+        // 144 K-steps each on 128x128 tiles (0.247 -> 0.215 and 0.143 -> 0.118 ms per 64 frames, profiles/r06_q_chain_k11.txt); same bits
+        if (k11 && tiles * (Cout_pad / 128) < 256) return CFG_H_128x64;
         return CFG_H_128x128;
     }
     // 64 output channels at 128x128 or more (G's last up block, F's first down block): 256-position tiles (16x16), two position waves x two

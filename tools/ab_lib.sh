@@ -4,7 +4,7 @@
 A=$1; B=$2; R=${3:-2}; TAG=${4:-ab_lib}
 cd /root/repo; mkdir -p gpurun_out/$TAG
 for i in $(seq $R); do for v in "$A" "$B"; do
-  CANONSWAP_LIB=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-fixed-job --no-cpu-baseline > gpurun_out/$TAG/b.json 2>gpurun_out/$TAG/b.err
+  CANONSWAP_LIB=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-fixed-job --no-cpu-baseline --no-chain --no-single-frame > gpurun_out/$TAG/b.json 2>gpurun_out/$TAG/b.err
   python - <<PY | tee -a gpurun_out/$TAG/ab.txt
 import json
 try:
@@ -13,7 +13,7 @@ except Exception as e: print("lib=[$v] failed", e, open("gpurun_out/$TAG/b.err")
 PY
 done; done
 k=0; for v in "$A" "$B"; do
-  CANONSWAP_LIB=$v CANONSWAP_PROFILE_CSV=/root/repo/gpurun_out/$TAG/layers_$k.csv timeout 600 python bench.py --no-cpu-baseline --no-fixed-job --steps 1 --warmup 2 > /dev/null 2>&1
+  CANONSWAP_LIB=$v CANONSWAP_PROFILE_CSV=/root/repo/gpurun_out/$TAG/layers_$k.csv timeout 600 python bench.py --no-cpu-baseline --no-fixed-job --no-chain --no-single-frame --steps 1 --warmup 2 > /dev/null 2>&1
   k=$((k+1))
 done
 python tools/cmp_layers.py gpurun_out/$TAG/layers_0.csv gpurun_out/$TAG/layers_1.csv 2>/dev/null | head -16 | tee gpurun_out/$TAG/cmp.txt

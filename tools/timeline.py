@@ -82,6 +82,29 @@ def cases(B, r):
                                out0=torch.empty(Bd, 16, 64, 64, 64, dtype=torch.float16, device=DEV), cfg=11, tile=(8, 8)), 108, 4 * 2, 2))
     out.append(("W.enc0_256", dict(x=xd[..., :112], w=wgt(112, 64, (3, 3, 3)), cout_pad=64, cout=64, k=(3, 3, 3), act0="relu", cin=112,
                                    out0=torch.empty(Bd, 16, 64, 64, 64, dtype=torch.float16, device=DEV), cfg=20, tile=(8, 8)), 108, 8 * 2, 2))
+    # G's last up block at 256 x 256 (64 output channels: c0 256 -> 64 with statistics, n1 SPADE 128 -> 2 x 64, c1 64 -> 64 + shortcut + lrelu copy) and
+    # the SPADE convs with 256 modulated channels at 128 / 256 (up_0.n1, up_1.n0); cfg / chunk size as pick_halo_cfg / go() choose them
+    Bu = min(B, 16)
+
+    def d0(t):      # the size-1 depth axis at stride 0, as the engine's nhwc() descriptors have it (axis strides are 24-bit quantities)
+        return t.as_strided(t.shape, (t.stride(0), 0, t.stride(2), t.stride(3), 1), t.storage_offset())
+    xu = d0(torch.relu(rn(Bu, 1, 256, 256, 256)))
+    sto = torch.empty(Bu * 2048 * 64 * 2 * 4, dtype=torch.float32, device=DEV)
+    out.append(("up1.c0", dict(x=xu, w=wgt(256, 64, (1, 3, 3)), cout_pad=64, cout=64, k=(1, 3, 3), bias=rn(64, dtype=np.float32), stat_out=sto,
+                               out0=d0(torch.empty(Bu, 1, 256, 256, 64, dtype=torch.float16, device=DEV)), cfg=20, tile=(16, 16)), 72, 8 * 2, 2))
+    a384 = d0(torch.relu(rn(Bu, 1, 256, 256, 384)))
+    st64 = torch.stack([rn(Bu, 64, dtype=np.float32), torch.rand(Bu, 64, device=DEV) + 0.5], dim=2).contiguous()
+    x64 = d0(rn(Bu, 1, 256, 256, 64))
+    out.append(("up1.n1", dict(x=a384[..., 128:256], w=wgt(128, 128, (1, 3, 3)), cout_pad=128, cout=64, k=(1, 3, 3), mode=2, bias=rn(64, dtype=np.float32),
+                               bias2=rn(64, dtype=np.float32), res=x64, stats=st64, act0="lrelu", slope0=0.2, ck=32,
+                               out0=d0(torch.empty(Bu, 1, 256, 256, 64, dtype=torch.float16, device=DEV)), cfg=10), 36, 8 * 2, 3))
+    for nm, cf, tl, mps, sl in (("up1.c1", 20, (16, 16), 8 * 2, 2), ("up1.c1s", 11, (0, 0), 4 * 2, 3)):
+        out.append((nm, dict(x=d0(torch.relu(x64)), w=wgt(64, 64, (1, 3, 3)), cout_pad=64, cout=64, k=(1, 3, 3), bias=rn(64, dtype=np.float32), res=x64,
+                             out1=d0(torch.empty(Bu, 1, 256, 256, 64, dtype=torch.float16, device=DEV)), act1="lrelu", slope1=0.2, cfg=cf, tile=tl), 18, mps, sl))
+    st256 = torch.stack([rn(Bu, 256, dtype=np.float32), torch.rand(Bu, 256, device=DEV) + 0.5], dim=2).contiguous()
+    out.append(("up1.n0", dict(x=a384[..., 0:128], w=wgt(128, 512, (1, 3, 3)), cout_pad=512, cout=256, k=(1, 3, 3), mode=2, bias=rn(256, dtype=np.float32),
+                               bias2=rn(256, dtype=np.float32), res=d0(rn(Bu, 1, 128, 128, 256)), res_shift=1, stats=st256, act0="lrelu", slope0=0.2,
+                               out0=d0(torch.empty(Bu, 1, 256, 256, 256, dtype=torch.float16, device=DEV)), cfg=17), 36, 8 * 4, 2))
     return out
 
 
