@@ -33,12 +33,13 @@ static inline int ep_check_extents(const ConvParams& p, const char* who)
     return 0;
 }
 
+__device__ __forceinline__ float gelu_act(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }      // nn.GELU (exact erf form)
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_LRELU) return v > 0.f ? v : v * slope;
     if (act == ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    if (act == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    if (act == ACT_GELU) return gelu_act(v);
     return v;
 }
 
@@ -286,7 +287,18 @@ _Pragma("unroll") \
 #ifndef EP_SPMUL_V
 #define EP_SPMUL_V 0
 #endif
+/* a kernel whose launches use the form "fp16 residual, no out0, second output only" (out1 = act1(conv + bias + res): the last conv of G's
+   up_1 block, whose only consumer is conv_img behind leaky_relu) and wants a branch-free copy of it sets EP_O1ONLY_V. */
+#ifndef EP_O1ONLY_V
+#define EP_O1ONLY_V 0
+#endif
+/* a kernel that runs the motion extractor's linear layers (1x1 convs in split precision, convnextv2.py:39-45: fp32 out0 with GELU; fp32 out0 +
+   fp32 residual in place; fp32 out0) and wants branch-free copies of those three forms sets EP_MLIN_V. */
+#ifndef EP_MLIN_V
+#define EP_MLIN_V 0
+#endif
 #define EP_SPMULB 256         /* EP_CODE bit: spmul */
+#define EP_GELUB 512          /* EP_CODE bit: act0 is GELU (kernels with EP_HEAVY: the motion extractor's pwconv1) */
 /* one fetch round of the epilogue: residual / modulated tensor / per-position scale of the position blocks PG0 .. PG0 + EP_G - 1 -> register set BI */
 #define EP_FETCH_ROUND(PG0, BI) \
     if (EP_PF && !EP_EARLY && (ep_fetch || ep_has_ps)) { \
@@ -320,6 +332,7 @@ _Pragma("unroll") \
     constexpr bool EPALL = EPFAST && ((EPF >> 6) & 1) == 0;      /* every channel of the wave exists */ \
     constexpr bool EP_POOL = EPFAST && ((EPF >> 7) & 1) != 0 && (EP_POOL_WSH_V) > 0;      /* out0 = AvgPool(1,2,2) of the activated values, on the pooled grid */ \
     constexpr int EP_PS = EP_POOL ? 1 : 0; \
+    constexpr bool EP_GELU = EPFAST && ((EPF >> 9) & 1) != 0;          /* act0 = GELU (EP_GELUB) */ \
     const bool ep_spm = EPFAST ? (((EPF >> 8) & 1) != 0) : ((MODE == MODE_STD) && p.spmul != 0); \
     constexpr bool EP_POOL_HB = EP_POOL && (EP_POOL_HSH_V) == 0;      /* 2-D tiles: the h + 1 neighbour is the same lane of the NEXT position block */ \
     float ep_phold[EP_POOL_HB ? WCH : 1][4];                           /* activated values of the even block, until the odd one arrives */ \
@@ -477,7 +490,9 @@ _Pragma("unroll") \
                 } \
             } \
 _Pragma("unroll") \
-            for (int r = 0; r < 4; ++r) v[r] = EP_HEAVY ? apply_act(v[r], p.act0, p.slope0) : lin_act(v[r], ep_sl0); \
+            /* branch-free copies know their activation: the linear family as one formula, or GELU (EP_GELUB); only the general epilogue of a \
+               kernel that carries sigmoid / GELU (EP_HEAVY) switches per element */ \
+            for (int r = 0; r < 4; ++r) v[r] = EP_GELU ? gelu_act(v[r]) : ((EP_HEAVY && !EPFAST) ? apply_act(v[r], p.act0, p.slope0) : lin_act(v[r], ep_sl0)); \
             if (MODE == MODE_PIXSHUF) { \
                 const int c = cb >> 2; \
                 if (c < 3) { \
@@ -575,10 +590,12 @@ _Pragma("unroll") \
             const int ep_chi = (ep_r0 + WCH * 16) / CST;              /* one past the wave's last output channel */ \
             const bool ep_call = ep_chi <= p.Cout && (p.Cout & 7) == 0; \
             const bool ep_ok = !p.ep_general && (ep_call || (EP_PAIR == 0 && (p.Cout & 3) == 0)) && (tn + 1) * (BM >> lgS) <= p.N && \
+                               (!EP_HEAVY || p.act0 <= ACT_LRELU || p.act0 == ACT_GELU) &&      /* (the copies carry the linear family or GELU, not sigmoid) */ \
                                (!p.res.p || p.res_f32 || EP_PAIR == 0 || ep_al8(p.res)) && \
                                (!p.out0.p || p.out0_f32 || EP_PAIR == 0 || ep_al8(p.out0)) && (!p.out1.p || EP_PAIR == 0 || ep_al8(p.out1)); \
             if (ep_ok) ep_code = EP_CODE(p.res.p ? (p.res_f32 ? 2 : 1) : 0, p.out0.p ? 1 : 0, p.out0_f32 ? 1 : 0, p.out1.p ? 1 : 0, p.pixscale ? 1 : 0) | \
-                                 (ep_call ? 0 : EP_RAGGED) | (p.pool_hw ? EP_POOLB : 0) | ((MODE == MODE_STD && p.spmul) ? EP_SPMULB : 0); \
+                                 (ep_call ? 0 : EP_RAGGED) | (p.pool_hw ? EP_POOLB : 0) | ((MODE == MODE_STD && p.spmul) ? EP_SPMULB : 0) | \
+                                 ((EP_HEAVY && p.act0 == ACT_GELU) ? EP_GELUB : 0); \
         } \
         bool ep_done = false; \
         if constexpr (EP_FAST && MODE == MODE_SPADE) { \
@@ -595,6 +612,14 @@ _Pragma("unroll") \
         } \
         if constexpr (EP_FAST && (MODE == MODE_STD || MODE == MODE_STDSTAT) && WCH != 5) { \
             if (ep_code == EP_CODE(1, 1, 0, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 1, 0, 0, 0)); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && MODE == MODE_STD && (EP_MLIN_V)) { \
+            if (ep_code == (EP_CODE(0, 1, 1, 0, 0) | EP_GELUB)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 0, 0) | EP_GELUB); ep_done = true; } \
+            if (ep_code == EP_CODE(0, 1, 1, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 0, 0)); ep_done = true; } \
+            if (ep_code == EP_CODE(2, 1, 1, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(2, 1, 1, 0, 0)); ep_done = true; } \
+        } \
+        if constexpr (EP_FAST && MODE == MODE_STD && (EP_O1ONLY_V)) { \
+            if (ep_code == EP_CODE(1, 0, 0, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 0, 0, 1, 0)); ep_done = true; } \
         } \
         if constexpr (EP_FAST && MODE == MODE_STD && WCH == 4) { \
             if (ep_code == EP_CODE(2, 1, 1, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(2, 1, 1, 1, 0)); ep_done = true; } \

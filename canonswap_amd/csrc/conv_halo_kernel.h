@@ -26,6 +26,8 @@
 #define EP_POOL_WSH_V EP_POOL_WSH_K      /* lane shifts of the pooling epilogue: per instantiation, from the lane -> position map (below) */
 #define EP_POOL_HSH_V EP_POOL_HSH_K
 #define EP_SPMUL_V EP_SPMUL_K            /* kernels that carry a branch-free copy of the spmul epilogue (below) */
+#define EP_MLIN_V EP_MLIN_K              /* kernels that carry branch-free copies of the motion extractor's three epilogue forms (below) */
+#define EP_O1ONLY_V EP_O1ONLY_K          /* kernels that carry a branch-free copy of the residual + second-output-only epilogue (below) */
 #define EP_O0_EXTRA_V ep_o0_extra        /* the output phase of a grouped launch (ConvParams::nphase; 0 otherwise) */
 #include "conv_epilogue.h"
 
@@ -205,6 +207,12 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #else
     constexpr bool EP_SPMUL_K = ST == 1 && !SK && MODE == MODE_STD && CK == 64 && WCH == 4 && WPX == 8 && WVP == 1;
 #endif
+    // G.up_1.conv_1 (64 -> 64 at 256 x 256; res + out1 = lrelu(.), no out0) ran the general epilogue: 21 000 of a wave's 41 000 cycles against
+    // 10 000 of main loop (profiles/r06_q_timeline_b64.txt); only the 2-D 256x64 kernel carries the copy
+    constexpr bool EP_O1ONLY_K = ST == 16 && !SK && MODE == MODE_STD;
+    // the 1x1 kernels (M's 39 linear layers: K of 9 - 288 steps per tile, so the epilogue is most of a tile's life; they ran the general epilogue with
+    // the per-element activation switch of EP_HEAVY)
+    constexpr bool EP_MLIN_K = ST == 15 && !SK && MODE == MODE_STD;
     constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : (EP_POOLK2 ? 1 : 0);
     constexpr int EP_POOL_HSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(SS::LW) : 0;
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
@@ -415,7 +423,7 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
 #ifdef CS_NO_EPFAST
     constexpr bool EP_FAST = false;
 #else
-    constexpr bool EP_FAST = !SK && ST != 0 && (WCH == 4 || WCH == 5 || (WCH == 2 && WPX == 8));
+    constexpr bool EP_FAST = !SK && ST != 0 && (WCH == 4 || WCH == 5 || (WCH == 2 && WPX == 8) || ST == 15);
 #endif
     constexpr int EP_WPX0 = WPX;
     const int ep_wpx0 = wpx;

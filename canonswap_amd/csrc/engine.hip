@@ -1196,7 +1196,9 @@ extern "C" int cs_finalize_weights(cs_engine* e)
                 TRY(get_f32(e, q + ".ln.g", C, &K.ln_g)); TRY(get_f32(e, q + ".ln.b", C, &K.ln_b));
                 TRY(get_f32(e, q + ".grn.g", 4 * C, &K.grn_g)); TRY(get_f32(e, q + ".grn.b", 4 * C, &K.grn_b));
                 TRY(get_conv(e, q + ".pw1", 3 * C, 4 * C, 4 * C, 1, 1, 1, 4 * C, (double)C * 4 * C, &K.pw1));   // split-precision: 3 x Cin
-                TRY(get_conv(e, q + ".pw2", 12 * C, C, C, 1, 1, 1, C, (double)C * 4 * C, &K.pw2));
+                // (stage 0: 96 output channels in one 128-channel block - 128x128 tiles stage a position's 1152 input channels once; as three
+                // 32-channel blocks on 128x32 tiles every block staged them again: 0.25 -> 0.17 ms per 64 frames; stage 1's 192 channels as two blocks instead of three 64-channel ones: 0.15 -> 0.16, not taken)
+                TRY(get_conv(e, q + ".pw2", 12 * C, C % 64 ? (C + 127) / 128 * 128 : C, C, 1, 1, 1, C, (double)C * 4 * C, &K.pw2));
             }
             if (i < 3) {
                 snprintf(n, sizeof n, "M.ds%d", i);

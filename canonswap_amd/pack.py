@@ -353,7 +353,7 @@ def _pack_M(out, sd):
             out[o + ".grn.g"] = _f32(sd[q + ".grn.gamma"].reshape(-1)); out[o + ".grn.b"] = _f32(sd[q + ".grn.beta"].reshape(-1))
             out[o + ".pw1.w"] = pack_conv(split_precision_weight(sd[q + ".pwconv1.weight"])[:, :, None, None], 4 * c)
             out[o + ".pw1.b"] = _f32(sd[q + ".pwconv1.bias"])
-            out[o + ".pw2.w"] = pack_conv(split_precision_weight(sd[q + ".pwconv2.weight"])[:, :, None, None], c)
+            out[o + ".pw2.w"] = pack_conv(split_precision_weight(sd[q + ".pwconv2.weight"])[:, :, None, None], c if c % 64 == 0 else -(-c // 128) * 128)   # stage 0: one 128-channel block (engine.hip)
             out[o + ".pw2.b"] = _f32(sd[q + ".pwconv2.bias"])
         if i < 3:
             q, o = f"{p}downsample_layers.{i + 1}", f"M.ds{i}"

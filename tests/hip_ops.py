@@ -6,7 +6,7 @@ import torch
 
 from canonswap_amd import _lib, pack
 
-ACT = {"none": 0, "relu": 1, "lrelu": 2, "sigmoid": 3}
+ACT = {"none": 0, "relu": 1, "lrelu": 2, "sigmoid": 3, "gelu": 4}
 
 
 def _p(t):

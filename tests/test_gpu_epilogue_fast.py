@@ -75,6 +75,65 @@ def test_std_fp32_res_two_outputs():
     _both(run)
 
 
+def test_std_res_second_output_only():
+    """G.up_1.conv_1 (64 -> 64 at 256 x 256 on the 2-D 256x64 tile): fp16 residual, no out0, out1 = leaky_relu(conv + bias + res, 0.2) -
+    the copy against the general epilogue, and both against fp32 torch on the fp16-rounded operands"""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(11)
+    N, S, C = 2, 64, 64
+    x = torch.relu(_t(r, N, 1, S, S, C))
+    w32 = (0.05 * r.standard_normal((C, C, 1, 3, 3))).astype(np.float32)
+    w = torch.from_numpy(pack.pack_conv(w32, C)).to(DEV)
+    b = _t(r, C, dtype=torch.float32)
+    rs = _t(r, N, 1, S, S, C)
+    got = []
+
+    def run(gen):
+        o1 = torch.zeros(N, 1, S, S, C, dtype=torch.float16, device=DEV)
+        ops.conv(x, w, C, C, (1, 3, 3), bias=b, res=rs, out1=o1, act1="lrelu", slope1=0.2, cfg=20, tile=(16, 16), ep_general=gen)
+        got.append(o1)
+        return [o1]
+    _both(run)
+    wh = torch.from_numpy(w32).half().float()[:, :, 0]
+    ref = torch.nn.functional.conv2d(x[:, 0].float().cpu().permute(0, 3, 1, 2), wh, b.cpu(), padding=1) + rs[:, 0].float().cpu().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.leaky_relu(ref, 0.2).permute(0, 2, 3, 1)
+    err = float((got[0][:, 0].float().cpu() - ref).abs().max())
+    assert err < 4e-3 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("cfg,ck", [(10, 64), (10, 32), (11, 64), (11, 32), (13, 64)])      # 128x128, 128x64, 128x32 tiles of the 1x1 kernels
+@pytest.mark.parametrize("form", ["gelu_f32", "f32", "res_f32_inplace", "sigmoid_f32"])
+def test_motion_linear_layers(cfg, ck, form):
+    """The motion extractor's 1x1 convs (convnextv2.py:39-45): fp32 output behind GELU, fp32 output, fp32 residual added in place - the
+    branch-free copies against the general epilogue (sigmoid: no copy exists, both runs take the general path), and against torch"""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(300 + cfg + ck + len(form))
+    N, S, Cin = 4, 16, 192
+    Cout = {10: 384, 11: 192, 13: 96}[cfg]
+    x = _t(r, N, 1, S, S, Cin)
+    w32 = (0.08 * r.standard_normal((Cout, Cin, 1, 1, 1))).astype(np.float32)
+    w = torch.from_numpy(pack.pack_conv(w32, Cout)).to(DEV)
+    b = _t(r, Cout, dtype=torch.float32)
+    rs0 = _t(r, N, 1, S, S, Cout, dtype=torch.float32)
+    act = {"gelu_f32": "gelu", "sigmoid_f32": "sigmoid"}.get(form, "none")
+    got = []
+
+    def run(gen):
+        o0 = rs0.clone() if form == "res_f32_inplace" else torch.zeros(N, 1, S, S, Cout, dtype=torch.float32, device=DEV)
+        ops.conv(x, w, Cout, Cout, (1, 1, 1), bias=b, act0=act, res=o0 if form == "res_f32_inplace" else None, out0=o0, cfg=cfg, ck=ck, ep_general=gen)
+        got.append(o0)
+        return [o0]
+    _both(run)
+    ref = x.float().cpu().reshape(-1, Cin) @ torch.from_numpy(w32).half().float().reshape(Cout, Cin).T + b.cpu()
+    ref = {"gelu": torch.nn.functional.gelu, "sigmoid": torch.sigmoid, "none": lambda t: t}[act](ref)
+    if form == "res_f32_inplace":
+        ref = ref + rs0.cpu().reshape(-1, Cout)
+    err = float((got[0].cpu().reshape(-1, Cout) - ref).abs().max())
+    assert err < 2e-3 * max(1.0, float(ref.abs().max())), err
+
+
 @pytest.mark.parametrize("xshift", [0, 1])
 def test_spade(xshift):
     """gamma / beta convs with the modulation epilogue on the 128x256 tile (the tensor being modulated at the same or half resolution)"""
