@@ -5,7 +5,7 @@ TAG=$1; shift
 cd /root/repo; O=gpurun_out/$TAG; mkdir -p $O
 for r in 1 2; do for v in "$@"; do
   n=$(basename "${v:-base}" .so)
-  CANONSWAP_LIB=$v timeout 300 python bench.py --batch 1 --latency-mode --steps 60 --warmup 10 --no-cpu-baseline --no-fixed-job 2>$O/$n.err | tail -1 > $O/$n.json
+  CANONSWAP_LIB=$v timeout 300 python bench.py --batch 1 --latency-mode --steps 60 --warmup 10 --no-cpu-baseline --no-fixed-job --no-chain --no-single-frame 2>$O/$n.err | tail -1 > $O/$n.json
   python - <<PY | tee -a $O/ab.txt
 import json
 try:
@@ -15,6 +15,6 @@ PY
 done; done
 for v in "$@"; do
   n=$(basename "${v:-base}" .so)
-  CANONSWAP_LIB=$v CANONSWAP_PROFILE_CSV=/root/repo/$O/layers_$n.csv timeout 300 python bench.py --batch 1 --latency-mode --no-cpu-baseline --no-fixed-job --steps 1 --warmup 2 > /dev/null 2>&1
+  CANONSWAP_LIB=$v CANONSWAP_PROFILE_CSV=/root/repo/$O/layers_$n.csv timeout 300 python bench.py --batch 1 --latency-mode --no-cpu-baseline --no-fixed-job --no-chain --no-single-frame --steps 1 --warmup 2 > /dev/null 2>&1
   python tools/layer_table.py $O/layers_$n.csv > $O/families_$n.txt
 done
