@@ -293,7 +293,7 @@ _Pragma("unroll") \
 #define EP_O1ONLY_V 0
 #endif
 /* a kernel that runs the motion extractor's linear layers (1x1 convs in split precision, convnextv2.py:39-45: fp32 out0 with GELU; fp32 out0 +
-   fp32 residual in place; fp32 out0) and wants branch-free copies of those three forms sets EP_MLIN_V. */
+   fp32 residual in place; fp32 out0) and wants branch-free copies of those three forms - and of F.second's (fp32 out0 + fp16 out1) - sets EP_MLIN_V. */
 #ifndef EP_MLIN_V
 #define EP_MLIN_V 0
 #endif
@@ -617,6 +617,7 @@ _Pragma("unroll") \
             if (ep_code == (EP_CODE(0, 1, 1, 0, 0) | EP_GELUB)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 0, 0) | EP_GELUB); ep_done = true; } \
             if (ep_code == EP_CODE(0, 1, 1, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 0, 0)); ep_done = true; } \
             if (ep_code == EP_CODE(2, 1, 1, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(2, 1, 1, 0, 0)); ep_done = true; } \
+            if (ep_code == EP_CODE(0, 1, 1, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 1, 0)); ep_done = true; }      /* F.second: fp32 volume + its fp16 copy */ \
         } \
         if constexpr (EP_FAST && MODE == MODE_STD && (EP_O1ONLY_V)) { \
             if (ep_code == EP_CODE(1, 0, 0, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 0, 0, 1, 0)); ep_done = true; } \

@@ -289,7 +289,7 @@ int pick_halo_cfg(const ConvParams& p, int mode)
             return CFG_H_128x64;
         // ... and the 1x1 convs up to one workgroup per CU: M's stage-3 pwconv2 and last down-sampling conv are 32 x 6 = 192 workgroups of 288 /
         // 144 K-steps each on 128x128 tiles (0.247 -> 0.215 and 0.143 -> 0.118 ms per 64 frames, profiles/r06_q_chain_k11.txt); same bits
-        if (k11 && tiles * (Cout_pad / 128) < 256) return CFG_H_128x64;
+        if (k11 && tiles * (Cout_pad / 128) < 256) return CFG_H_128x64;      // (up to 768 - fewer workgroups than resident slots - measured the same)
         return CFG_H_128x128;
     }
     // 64 output channels at 128x128 or more (G's last up block, F's first down block): 256-position tiles (16x16), two position waves x two
