@@ -149,6 +149,11 @@ int launch_dm_compress(const float* f, const float* w, const float* b, half_t* c
     return 0;
 }
 
+__device__ __forceinline__ float sqdist3(float a, float b, float c)
+{
+#pragma clang fp contract(off)
+    return (a * a + b * b) + c * c;
+}
 __device__ __forceinline__ float grid_coord(int i, int n) { return 2.f * ((float)i / (float)(n - 1)) - 1.f; }  // util.py:48-50
 
 // Fused create_sparse_motions + create_deformed_feature + create_heatmap_representations + concat
@@ -175,41 +180,86 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
     const long v0 = (((long)n * D + d) * H + y) * W;         // first voxel of the row
     const float gx = grid_coord(x, W), gy = grid_coord(y, H), gz = grid_coord(d, D);
     const half_t* base = comp + (long)n * comp_sN;
-    for (int k = t >> 6; k < 23; k += 4) {                   // wave-uniform slot
+    // Round 6 (second pass): what a slot's sample shares over the row - its key-points, the y and z coordinates with their corner weights,
+    // clamps and offsets - is formed ONCE per wave, by lane k for slot k, and handed to the slot loop through v_readlane (the slot is
+    // wave-uniform): the loop keeps the x axis, the heat map and the gather.  The compiler cannot do this itself (no scalar float unit on
+    // gfx950: wave-uniform float arithmetic runs on all 64 lanes); the kernel is VALU-bound (198 vector instructions per slot and row before,
+    // 0.58 ms per 64-frame call).  The same operations on the same values in the same order: same bits (tools/cmp_libs.py).
+    const int lane = t & 63;
+    float u_pd[3] = {0.f, 0.f, 0.f}, u_ps[3] = {0.f, 0.f, 0.f};
+    if (lane >= 1 && lane <= 21) {
+        const float* pd = kp_d + ((long)n * 21 + (lane - 1)) * 3;
+        const float* ps = kp_s + (long)n * kps_sN + (lane - 1) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { u_pd[a] = pd[a]; u_ps[a] = ps[a]; }
+    }
+    float u_wy[2], u_wz[2]; unsigned u_oyz[4];
+    {
+        float sy = gy, sz = gz;
+        if (lane > 0) { sy = (gy - u_pd[1]) + u_ps[1]; sz = (gz - u_pd[2]) + u_ps[2]; }
+        const float iy = ((sy + 1.f) * H - 1.f) * 0.5f, iz = ((sz + 1.f) * D - 1.f) * 0.5f;
+        const float fy = floorf(iy), fz = floorf(iz);
+        const int y0 = (int)fy, z0 = (int)fz;
+        const float ty = iy - fy, tz = iz - fz;
+        unsigned oy[2], oz[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int yc = y0 + q, zc = z0 + q;
+            u_wy[q] = (unsigned)yc < (unsigned)H ? (q ? ty : 1.f - ty) : 0.f;
+            u_wz[q] = (unsigned)zc < (unsigned)D ? (q ? tz : 1.f - tz) : 0.f;
+            oy[q] = (unsigned)(min(max(yc, 0), H - 1) * (W * 8));           // byte offsets (4 fp16 channels per voxel)
+            oz[q] = (unsigned)(min(max(zc, 0), D - 1) * (H * W * 8));
+        }
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) u_oyz[dz * 2 + dy] = oz[dz] + oy[dy];
+    }
+    for (int k = __builtin_amdgcn_readfirstlane(t >> 6); k < 23; k += 4) {                   // wave-uniform slot
+        // (all lanes take part in the lane reads; lanes beyond the row only skip the stores)
+        float pd[3], ps[3], wy[2], wz[2]; unsigned oyz[4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            pd[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u_pd[a]), k));
+            ps[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u_ps[a]), k));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wy[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u_wy[q]), k));
+            wz[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u_wz[q]), k));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) oyz[q] = (unsigned)__builtin_amdgcn_readlane((int)u_oyz[q], k);
         if (x >= W) continue;
         half_t* o = tile + x * RS + k * 5;
         if (k == 22) { o[0] = (half_t)0.f; o[1] = (half_t)0.f; continue; }
-        float sx = gx, sy = gy, sz = gz, heat = 0.f;
+        float sx = gx, heat = 0.f;
         if (k > 0) {
-            const float* pd = kp_d + ((long)n * 21 + (k - 1)) * 3;
-            const float* ps = kp_s + (long)n * kps_sN + (k - 1) * 3;
-            sx = (gx - pd[0]) + ps[0]; sy = (gy - pd[1]) + ps[1]; sz = (gz - pd[2]) + ps[2];
-            const float dd = (gx - pd[0]) * (gx - pd[0]) + (gy - pd[1]) * (gy - pd[1]) + (gz - pd[2]) * (gz - pd[2]);
-            const float ds = (gx - ps[0]) * (gx - ps[0]) + (gy - ps[1]) * (gy - ps[1]) + (gz - ps[2]) * (gz - ps[2]);
+            sx = (gx - pd[0]) + ps[0];
+            // (the squared distances in the reference's order with every product rounded - torch's (grid - kp) ** 2 summed over the last axis,
+            // util.py:31-35: left to the compiler, which of the products fused into an FMA depended on how it happened to pair the axes)
+            const float dd = sqdist3(gx - pd[0], gy - pd[1], gz - pd[2]);
+            const float ds = sqdist3(gx - ps[0], gy - ps[1], gz - ps[2]);
             heat = __expf(-0.5f * dd / 0.01f) - __expf(-0.5f * ds / 0.01f);   // util.py:36 kp_variance = 0.01
         }
         // F.grid_sample(..., align_corners=False), trilinear, zeros padding (dense_motion.py:50)
-        const float ix = ((sx + 1.f) * W - 1.f) * 0.5f, iy = ((sy + 1.f) * H - 1.f) * 0.5f, iz = ((sz + 1.f) * D - 1.f) * 0.5f;
-        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-        const float tx = ix - fx, ty = iy - fy, tz = iz - fz;
+        const float ix = ((sx + 1.f) * W - 1.f) * 0.5f;
+        const float fx = floorf(ix);
+        const int x0 = (int)fx;
+        const float tx = ix - fx;
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         // The eight corners are fetched unconditionally (clamped address, weight 0 outside the volume: fmaf(0, c, a) == a, the same bits as
         // skipping the corner) so that the loads go out back to back; behind a bounds test each one waited for its own round trip.  Bounds,
         // clamps and address terms are formed per AXIS (six of each, not twenty-four); a corner's weight is ((wx * wy) * wz) with the
         // out-of-range factor replaced by 0 - the same bits as the product of the three factors followed by the bounds select (all
-        // factors are >= 0, so the zero is +0 either way; tools/dbg_hash.py printed the same hashes).  No faster than the per-corner form:
-        // the kernel is not VALU-bound.
-        float wx[2], wy[2], wz[2]; int ox[2], oy[2], oz[2];
+        // factors are >= 0, so the zero is +0 either way; tools/dbg_hash.py printed the same hashes).  Offsets are unsigned 32-bit byte
+        // counts from the sample's base (a scalar): the loads take the SGPR-base + VGPR-offset form, no 64-bit address per corner.
+        float wx[2]; unsigned ox[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int xc = x0 + q, yc = y0 + q, zc = z0 + q;
+            const int xc = x0 + q;
             wx[q] = (unsigned)xc < (unsigned)W ? (q ? tx : 1.f - tx) : 0.f;
-            wy[q] = (unsigned)yc < (unsigned)H ? (q ? ty : 1.f - ty) : 0.f;
-            wz[q] = (unsigned)zc < (unsigned)D ? (q ? tz : 1.f - tz) : 0.f;
-            ox[q] = min(max(xc, 0), W - 1) * 4;
-            oy[q] = min(max(yc, 0), H - 1) * (W * 4);
-            oz[q] = min(max(zc, 0), D - 1) * (H * W * 4);
+            ox[q] = (unsigned)(min(max(xc, 0), W - 1) * 8);
         }
         h4_t cv[8]; float wv[8];
 #pragma unroll
@@ -218,7 +268,7 @@ __global__ void __launch_bounds__(256) dm_sparse_kernel(const half_t* __restrict
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    cv[dz * 4 + dy * 2 + dx] = *(const h4_t*)(base + (oz[dz] + oy[dy] + ox[dx]));
+                    cv[dz * 4 + dy * 2 + dx] = *(const h4_t*)((const char*)base + (oyz[dz * 2 + dy] + ox[dx]));
                     wv[dz * 4 + dy * 2 + dx] = (wx[dx] * wy[dy]) * wz[dz];
                 }
 #pragma unroll
