@@ -358,6 +358,11 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP engine has not been built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(needs hipcc); canonswap_amd has no CPU fallback.")
+    # The process must hold ONE HIP runtime.  This package's callers pass torch tensors and torch's stream, and torch carries its own
+    # libamdhip64 / libhsa-runtime64: imported first, its copies satisfy this library's NEEDED entries too.  Loaded the other way round (this
+    # library first - `python __graft_entry__.py smoke`, whose build() checks the ABI before anything imports torch) the system runtime and
+    # torch's both initialise and cs_create sees 0 devices.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     if lib.cs_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} speaks C-ABI version {lib.cs_abi_version()}, this package binds version {ABI_VERSION} "
