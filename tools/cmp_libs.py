@@ -1,4 +1,5 @@
-"""GPU box: the same frames through two builds of the library, compared bit for bit (stage outputs of the whole loop body, default and latency mode):
+"""GPU box: the same frames through two builds of the library, compared bit for bit (stage outputs of the whole loop body, default and latency mode,
+and the motion extractor's raw head outputs):
     python tools/cmp_libs.py tools/bin/base.so ""        ("" = the shipped library)
 Each build runs in its own process (the library is chosen at import: CANONSWAP_LIB)."""
 import os
@@ -25,6 +26,9 @@ for lat in (False, True):
     for k, v in r.items():
         if torch.is_tensor(v):
             out[("lat." if lat else "") + k] = v.cpu()
+sdm = synth.to_torch(synth.make_state_dicts(0, modules=synth.MODULES + ("motion_extractor",)))
+swm = can_swapper(None, state_dicts=sdm, max_batch=5)
+out["M.raw"] = swm.engine.motion_extract_raw(torch.from_numpy(synth.make_smooth_images(5, seed=77, size=256)).cuda()).cpu()
 torch.save(out, sys.argv[1])
 ''' % ROOT
 
