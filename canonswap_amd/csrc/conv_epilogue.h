@@ -297,6 +297,11 @@ _Pragma("unroll") \
 #ifndef EP_MLIN_V
 #define EP_MLIN_V 0
 #endif
+/* a kernel whose launches write the same fp16 values twice (out0 and, through the identity second affine, out1: the duplicate output rows of
+   mlp_shared on a x4 up-sampled map, engine.hip run_G) and wants a branch-free copy of that form sets EP_DUP_V. */
+#ifndef EP_DUP_V
+#define EP_DUP_V 0
+#endif
 #define EP_SPMULB 256         /* EP_CODE bit: spmul */
 #define EP_GELUB 512          /* EP_CODE bit: act0 is GELU (kernels with EP_HEAVY: the motion extractor's pwconv1) */
 /* one fetch round of the epilogue: residual / modulated tensor / per-position scale of the position blocks PG0 .. PG0 + EP_G - 1 -> register set BI */
@@ -408,7 +413,7 @@ _Pragma("unroll") \
                                            __mul24((ep_h0 + ep_lh) >> EP_PS, (int)p.out0.sH) + __mul24((ep_w0 + ep_lw) >> EP_PS, (int)p.out0.sW)); \
     /* pooled: the lanes whose position is the (even h, even w) corner of a window hold the window's sum and store it */ \
     const bool ep_pool_lane = !EP_POOL || (lane & ((EP_POOL_WSH_V) | (EP_POOL_HSH_V))) == 0; \
-    const unsigned ep_lane_o1 = (unsigned)(ep_nb * (int)p.out1.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out1.sN) + __mul24(ep_d0 + ep_ld, (int)p.out1.sD) + \
+    const unsigned ep_lane_o1 = (EP_O0_EXTRA_V) + (unsigned)(ep_nb * (int)p.out1.sN + (ep_tn1 ? 0 : ep_ln * (int)p.out1.sN) + __mul24(ep_d0 + ep_ld, (int)p.out1.sD) + \
                                            __mul24(ep_h0 + ep_lh, (int)p.out1.sH) + __mul24(ep_w0 + ep_lw, (int)p.out1.sW)); \
     const unsigned ep_lane_ps = (unsigned)(((((ep_nb + ep_ln) * p.D + ep_d0 + ep_ld) * p.H + ep_h0 + ep_lh) * p.W + ep_w0 + ep_lw) * p.ps_stride); \
     /* pixel shuffle: out[n][c][2h + i][2w + j], H2 = 2H, W2 = 2W */ \
@@ -618,6 +623,9 @@ _Pragma("unroll") \
             if (ep_code == EP_CODE(0, 1, 1, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 0, 0)); ep_done = true; } \
             if (ep_code == EP_CODE(2, 1, 1, 0, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(2, 1, 1, 0, 0)); ep_done = true; } \
             if (ep_code == EP_CODE(0, 1, 1, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 1, 1, 0)); ep_done = true; }      /* F.second: fp32 volume + its fp16 copy */ \
+        } \
+        if constexpr (EP_FAST && MODE == MODE_STD && (EP_DUP_V)) { \
+            if (ep_code == EP_CODE(0, 1, 0, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(0, 1, 0, 1, 0)); ep_done = true; } \
         } \
         if constexpr (EP_FAST && MODE == MODE_STD && (EP_O1ONLY_V)) { \
             if (ep_code == EP_CODE(1, 0, 0, 1, 0)) { CONV_EPILOGUE_IMPL(EP_CODE(1, 0, 0, 1, 0)); ep_done = true; } \

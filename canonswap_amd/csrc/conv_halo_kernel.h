@@ -26,6 +26,7 @@
 #define EP_POOL_WSH_V EP_POOL_WSH_K      /* lane shifts of the pooling epilogue: per instantiation, from the lane -> position map (below) */
 #define EP_POOL_HSH_V EP_POOL_HSH_K
 #define EP_SPMUL_V EP_SPMUL_K            /* kernels that carry a branch-free copy of the spmul epilogue (below) */
+#define EP_DUP_V EP_DUP_K                /* kernels that carry a branch-free copy of the two-identical-outputs epilogue (below) */
 #define EP_MLIN_V EP_MLIN_K              /* kernels that carry branch-free copies of the motion extractor's three epilogue forms (below) */
 #define EP_O1ONLY_V EP_O1ONLY_K          /* kernels that carry a branch-free copy of the residual + second-output-only epilogue (below) */
 #define EP_O0_EXTRA_V ep_o0_extra        /* the output phase of a grouped launch (ConvParams::nphase; 0 otherwise) */
@@ -213,6 +214,9 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     // the 1x1 kernels (M's 39 linear layers: K of 9 - 288 steps per tile, so the epilogue is most of a tile's life; they ran the general epilogue with
     // the per-element activation switch of EP_HEAVY)
     constexpr bool EP_MLIN_K = ST == 15 && !SK && MODE == MODE_STD;
+    // the per-phase convs of mlp_shared with one source row (ST 14 / 15: 1x1x2 and 1x1x1 taps): output rows 4i + 1 and 4i + 2 of the x4 level are the
+    // same values - one launch writes both (out1 through the identity second affine) instead of two launches computing them
+    constexpr bool EP_DUP_K = (ST == 14 || ST == 15) && !SK && MODE == MODE_STD && WCH == 2 && WPX == 8;
     constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : (EP_POOLK2 ? 1 : 0);
     constexpr int EP_POOL_HSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(SS::LW) : 0;
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel
@@ -1247,8 +1251,8 @@ static int launch_halo_st(const ConvParams& p, hipStream_t st)
     }
     if (p.nphase) {
         if (SK || !halo_phase_group<WCH, ST>() || p.nphase < 1 || p.nphase > 4 || p.sk_out || p.kw_out || p.xs_w || p.persist_total < 0) { cs_set_error("conv_halo: bad grouped launch (%d phases)", p.nphase); return -1; }
-        // the phase's output offset is applied to out0 only: every other tensor of the epilogue would be read / written at the same addresses by all phases
-        if (p.res.p || p.out1.p || p.stat_out || p.pixscale || p.spmul || p.pool_hw) { cs_set_error("conv_halo: a grouped launch carries out0 only (no res / out1 / statistics / pixel scale / spmul / pooling)"); return -1; }
+        // the phase's output offset is applied to out0 and out1: every other tensor of the epilogue would be read / written at the same addresses by all phases
+        if (p.res.p || p.stat_out || p.pixscale || p.spmul || p.pool_hw) { cs_set_error("conv_halo: a grouped launch carries out0 / out1 only (no res / statistics / pixel scale / spmul / pooling)"); return -1; }
         for (int z = 0; z < p.nphase; ++z)
             if (p.ph_ooff[z] % 8u) { cs_set_error("conv_halo: output offset of phase %d (%u elements) is not a multiple of 8 (16-byte stores)", z, p.ph_ooff[z]); return -1; }
         grid.z = (unsigned)p.nphase;

@@ -927,23 +927,33 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
         const int sc = lv ? 4 : 2, S = 64 * sc;
         half_t* dst = lv ? e->g_a256 : e->g_a128;
         bool done[16] = {};
+        // x4 level: output rows 4i + 1 and 4i + 2 read source row i alone - the same taps, the same summed weights (pack.upsampled_conv_phases),
+        // the same values.  The a = 1 launches write both rows (out1 = the row below, through the identity second affine); the a = 2 phases
+        // are not launched: 12 phase convs -> 9, same bits (CANONSWAP_SHARED_DEDUP=0: A/B, all twelve)
+        static const bool dedup = [] { const char* s = getenv("CANONSWAP_SHARED_DEDUP"); return !s || atoi(s) != 0; }();
+        const bool dd = dedup && sc == 4;
         for (int k = 0; k < e->g_nshp[lv]; ++k) {
+            if (dd && e->g_shp[lv][k].a == 2) done[k] = true;
             if (done[k]) continue;
             const cs_engine::ShPhase& P = e->g_shp[lv][k];
+            const bool dup = dd && P.a == 1;
             ConvCall c = mk(P.conv, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
+            if (dup) c.macs_per_pos *= 2;      // (the reference's count: this launch stands for two output rows)
             c.p.PH = P.ph; c.p.PW = P.pw;
             c.p.act0 = ACT_RELU;
             // output pixel (sc*i + a, sc*j + b0 + k), channel c  <-  source position (i, j), channel k*384 + c
             if (!sh_grouped) {
                 c.p.out0 = td(dst + ((long)P.a * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+                if (dup) c.p.out1 = td(dst + ((long)(P.a + 1) * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
                 TRY(go(e, c, st));
                 continue;
             }
             c.p.out0 = td(dst, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+            if (dup) c.p.out1 = td(dst + (long)S * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);      // (the phase offset applies to both)
             int n = 0;
             for (int j = k; j < e->g_nshp[lv] && n < 4; ++j) {
                 const cs_engine::ShPhase& Q = e->g_shp[lv][j];
-                if (done[j] || Q.conv.KH != P.conv.KH || Q.conv.KW != P.conv.KW || Q.conv.Cout_pad != P.conv.Cout_pad) continue;
+                if (done[j] || Q.conv.KH != P.conv.KH || Q.conv.KW != P.conv.KW || Q.conv.Cout_pad != P.conv.Cout_pad || (dd && Q.a == 2)) continue;
                 done[j] = true;
                 c.p.ph_wofs[n] = (long)(((intptr_t)Q.conv.w - (intptr_t)P.conv.w) / (intptr_t)sizeof(half_t));
                 c.p.ph_ooff[n] = (unsigned)(((long)Q.a * S + Q.b0) * 384);
