@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(256, (WCH == 4 ? 2 : ((WCH == 2 && WPX == 8 &&
     constexpr bool EP_MLIN_K = ST == 15 && !SK && MODE == MODE_STD;
     // the per-phase convs of mlp_shared with one source row (ST 14 / 15: 1x1x2 and 1x1x1 taps): output rows 4i + 1 and 4i + 2 of the x4 level are the
     // same values - one launch writes both (out1 through the identity second affine) instead of two launches computing them
-    constexpr bool EP_DUP_K = (ST == 14 || ST == 15) && !SK && MODE == MODE_STD && WCH == 2 && WPX == 8;
+    // (ST 11, 1x2x1 taps: the two middle column phases of a two-row phase - one value for two neighbouring pixels)
+    constexpr bool EP_DUP_K = (ST == 11 || ST == 14 || ST == 15) && !SK && MODE == MODE_STD && WCH == 2 && WPX == 8;
     constexpr int EP_POOL_WSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(0) : (EP_POOLK2 ? 1 : 0);
     constexpr int EP_POOL_HSH_K = EP_POOLK ? halo_pool_shift<ST, PAD>(SS::LW) : 0;
     constexpr int VS = SLP * 16;         // LDS bytes per halo voxel

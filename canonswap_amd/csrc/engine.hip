@@ -83,7 +83,9 @@ struct cs_engine {
     struct S3 { ConvL c1, c2, c1sp, c2sp; const float *g1, *b1, *g2, *b2; } r_s1[3], r_s3[3];   // *sp: split-precision weights (Cin 96)
     struct RB2 { ConvL c1, c2; Affine pre; } r_rb2[3];
     ConvL g_fc, g_sh64, g_sh128, g_sh256, g_img;
-    struct ShPhase { ConvL conv; int a, b0, ph, pw; };     // mlp_shared convs of the up blocks per output phase group on the source grid
+    // mlp_shared convs of the up blocks per output phase group on the source grid; dupc: the value also goes to the next pixel (x4 level, middle
+    // columns of a two-row phase)
+    struct ShPhase { ConvL conv; int a, b0, ph, pw; bool dupc; };
     ShPhase g_shp[2][12]; int g_nshp[2] = {0, 0};
     struct GB { ConvL conv; const float *bg, *bb; };
     struct SpadeBlk { GB n0, n1, ns; ConvL c0, c1, cs, ng, bs; bool learned; int fin, fmid, fout; } g_blk[8];      // ng / bs: the learned shortcut's norm_s, see run_G
@@ -936,7 +938,7 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
             if (dd && e->g_shp[lv][k].a == 2) done[k] = true;
             if (done[k]) continue;
             const cs_engine::ShPhase& P = e->g_shp[lv][k];
-            const bool dup = dd && P.a == 1;
+            const bool dup = dd && P.a == 1, dupc = P.dupc;      // (a phase duplicates its row or its pixel, not both: one second output)
             ConvCall c = mk(P.conv, seg, nhwc(nullptr, 64, 64, 256), B, 1, 64, 64);
             if (dup) c.macs_per_pos *= 2;      // (the reference's count: this launch stands for two output rows)
             c.p.PH = P.ph; c.p.PW = P.pw;
@@ -945,15 +947,17 @@ int run_G(cs_engine* e, int B, const half_t* seg, float* img, hipStream_t st)
             if (!sh_grouped) {
                 c.p.out0 = td(dst + ((long)P.a * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
                 if (dup) c.p.out1 = td(dst + ((long)(P.a + 1) * S + P.b0) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
+                if (dupc) c.p.out1 = td(dst + ((long)P.a * S + P.b0 + 1) * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
                 TRY(go(e, c, st));
                 continue;
             }
             c.p.out0 = td(dst, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
             if (dup) c.p.out1 = td(dst + (long)S * 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);      // (the phase offset applies to both)
+            if (dupc) c.p.out1 = td(dst + 384, (long)S * S * 384, 0, (long)sc * S * 384, (long)sc * 384);
             int n = 0;
             for (int j = k; j < e->g_nshp[lv] && n < 4; ++j) {
                 const cs_engine::ShPhase& Q = e->g_shp[lv][j];
-                if (done[j] || Q.conv.KH != P.conv.KH || Q.conv.KW != P.conv.KW || Q.conv.Cout_pad != P.conv.Cout_pad || (dd && Q.a == 2)) continue;
+                if (done[j] || Q.conv.KH != P.conv.KH || Q.conv.KW != P.conv.KW || Q.conv.Cout_pad != P.conv.Cout_pad || (dd && Q.a == 2) || Q.dupc != P.dupc) continue;
                 done[j] = true;
                 c.p.ph_wofs[n] = (long)(((intptr_t)Q.conv.w - (intptr_t)P.conv.w) / (intptr_t)sizeof(half_t));
                 c.p.ph_ooff[n] = (unsigned)(((long)Q.a * S + Q.b0) * 384);
@@ -1323,9 +1327,12 @@ extern "C" int cs_finalize_weights(cs_engine* e)
                 const int nb = edge ? 1 : sc - 2, kw = edge ? 2 : 1, pw = b0 == 0 ? 1 : 0;
                 cs_engine::ShPhase& P = e->g_shp[lv][e->g_nshp[lv]++];
                 P.a = a; P.b0 = b0; P.ph = ph; P.pw = pw;
+                // x4 level: the two middle column phases of a two-row phase are the same values - packed once (pack._pack_G), written twice (run_G)
+                P.dupc = sc == 4 && nb == 2 && kh == 2;
+                const int nbw = P.dupc ? 1 : nb;
                 snprintf(n, sizeof n, "G.shared%d.p%d%d", lv ? 256 : 128, a, b0);
                 // algorithmic MACs stay those of the 3x3 conv on the up-sampled grid: nb*sc... output pixels per source position
-                TRY(get_conv(e, n, 256, nb * 384, nb * 384, 1, kh, kw, nb * 384, 256.0 * 384 * 9 * nb, &P.conv));
+                TRY(get_conv(e, n, 256, nbw * 384, nbw * 384, 1, kh, kw, nbw * 384, 256.0 * 384 * 9 * nb, &P.conv));
                 b0 += nb;
             }
         }

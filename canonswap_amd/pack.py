@@ -295,6 +295,13 @@ def _pack_G(out, sd):
         s_up = {"G.shared128": 2, "G.shared256": 4}.get(n)
         if s_up:      # the same convs per output row phase on the 64x64 source grid (2.25x / 4x fewer taps, engine.hip run_G)
             for a, b0, nb, kh, ph, kw, pw, wg in upsampled_conv_phases(w, s_up):
+                # x4 level, two-row phases (a = 0, 3): the column phases of the middle group read the same source column with the same summed
+                # weights - one copy is packed, the engine's launch writes the value to both pixels (run_G); the one-row phase a = 1 keeps both
+                # copies as output-channel blocks, its second output is taken by the duplicate ROW (a = 2 is never launched)
+                if s_up == 4 and nb == 2 and a in (0, 3):
+                    co = wg.shape[0] // nb
+                    assert np.array_equal(wg[:co], wg[co:])
+                    wg, nb = wg[:co], 1
                 out[f"{n}.p{a}{b0}.w"] = pack_conv(wg, wg.shape[0])
                 out[f"{n}.p{a}{b0}.b"] = _f32(np.tile(out[n + ".b"], nb))
     blocks = [(f"G.m{b}", f"G_middle_{b}") for b in range(6)] + [("G.up0", "up_0"), ("G.up1", "up_1")]

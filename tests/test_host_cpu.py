@@ -152,6 +152,12 @@ def test_upsampled_conv_phase_decomposition(s):
         for k in range(nb):
             out[:, :, a::s, b0 + k::s] = y[:, k * 5:(k + 1) * 5]
     assert np.abs(out - ref).max() < 1e-12
+    if s == 4:      # what run_G's de-duplication rests on: rows 4i+1 / 4i+2 and the two middle columns carry the same weights, bit for bit
+        by = {(a, b0): wg for a, b0, nb, kh, ph, kw, pw, wg in phases}
+        for b0 in (0, 1, 3):
+            assert np.array_equal(by[(1, b0)], by[(2, b0)])
+        for a in range(4):
+            assert np.array_equal(by[(a, 1)][:5], by[(a, 1)][5:])
 
 
 def test_upsampled_conv3d_phase_decomposition():
