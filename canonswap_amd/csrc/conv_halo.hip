@@ -51,6 +51,8 @@ GROUP_FN(0)     // special shapes that take precedence over the generic table: p
     if (p.KD == 3 && p.KH == 2 && p.KW == 2 && ck == 32 && mode == MODE_STD) {
         if (cfg == CFG_H_256x32) return launch_halo_cfg<32, 4, 2, 4, 1, MODE_STD, false, 12>(p, st);
         if (cfg == CFG_H_128x64) return launch_halo_cfg<32, 4, 2, 2, 2, MODE_STD, false, 13>(p, st);
+        if (cfg == CFG_H_128x128 && p.lgTW == 2) return launch_halo_cfg<32, 8, 2, 1, 4, MODE_STD, false, 17>(p, st);      // up-block 0 (512 channels, 4x4 source grid)
+        if (cfg == CFG_H_128x128) return launch_halo_cfg<32, 8, 2, 1, 4, MODE_STD, false, 13>(p, st);      // up-blocks 1 / 2 (256 / 128 channels)
     }
     if (mode == MODE_STD && p.KD == 1 && p.KH == 1 && p.KW == 1) {      // 1x1 convs (shortcuts, the motion extractor's linear layers)
         if (cfg == CFG_H_128x128 && ck == 32) return launch_halo_cfg<32, 8, 2, 1, 4, MODE_STD, false, 15>(p, st);

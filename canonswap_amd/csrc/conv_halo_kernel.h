@@ -64,7 +64,7 @@ extern long g_cs_tl_cap;
 //   ST 4: 7x7x1 (the kw-split mask conv), tile 8x8x2            ST 5: 3x3x3, tile 4x4x8 (4x4 hourglass level)
 //   ST 6: 7x7x1, tile 2x8x8 (no halo along W: 392 halo voxels instead of 896, double-buffered)
 //   ST 16: 1x3x3, tile 16x16 (256 positions x 64 channels: the 64-channel 3x3 convs of G's last up block and F's first down block)
-//   ST 12 / 13: 3x2x2, tiles 4x4x16 and 8x8x2 (the hourglass up-blocks per output phase on the source grid)
+//   ST 12 / 13 / 17: 3x2x2, tiles 4x4x16, 8x8x2 and 4x4x8 (the hourglass up-blocks per output phase on the source grid)
 //   ST 10 / 11 / 14 / 15: 1x2x2, 1x2x1, 1x1x2, 1x1x1, tile 16x8 (the per-phase convs of mlp_shared on the up-sampled seg, run_G)
 template <int ST> struct StaticShape { static constexpr int KD = 0, KH = 0, KW = 0, LW = 0, LH = 0, LD = 0; };
 template <> struct StaticShape<1> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 3, LD = 0; };
@@ -79,6 +79,7 @@ template <> struct StaticShape<9> { static constexpr int KD = 7, KH = 7, KW = 1,
 template <> struct StaticShape<16> { static constexpr int KD = 1, KH = 3, KW = 3, LW = 4, LH = 4, LD = 0; };   // 256 positions: 16x16 (2-D)
 template <> struct StaticShape<12> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 4; };
 template <> struct StaticShape<13> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 3, LH = 3, LD = 1; };
+template <> struct StaticShape<17> { static constexpr int KD = 3, KH = 2, KW = 2, LW = 2, LH = 2, LD = 3; };   // 3x2x2, tile 4x4x8 (up-block 0 of the hourglass per phase: 4x4 source grid)
 template <> struct StaticShape<10> { static constexpr int KD = 1, KH = 2, KW = 2, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<11> { static constexpr int KD = 1, KH = 2, KW = 1, LW = 4, LH = 3, LD = 0; };
 template <> struct StaticShape<14> { static constexpr int KD = 1, KH = 1, KW = 2, LW = 4, LH = 3, LD = 0; };

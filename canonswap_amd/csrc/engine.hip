@@ -75,7 +75,7 @@ struct cs_engine {
     struct RB3 { ConvL c1, c2; Affine post; } f_rb[6], t_rb[6];
     const float *cmp_w = nullptr, *cmp_b = nullptr;
     ConvL w_enc[5], w_dec[5], w_tail, w_mask, w_occ, w_occ49, w_third, w_fourth;
-    ConvL w_dec_p[2][4];                   // up-blocks 3 and 4 per output phase (a, b) on the source grid
+    ConvL w_dec_p[5][4];                   // the up-blocks per output phase (a, b) on the source grid
     float occ_b = 0.f;
     const float* mask_b = nullptr;
     TLayer t_l[14];
@@ -553,6 +553,9 @@ int run_F(cs_engine* e, int B, const float* img, int* cur, hipStream_t st)
 // kernel (dm_softmax_warp_kernel): the caller launches no grid_sample.
 bool warp_fused() { static const bool on = [] { const char* s = getenv("CANONSWAP_WARP_FUSED"); return !s || atoi(s) != 0; }(); return on; }
 
+// CANONSWAP_DEC_PHASES_DEEP=0: A/B knob (up-blocks 0 - 2 of the hourglass as 27-tap convs on the up-sampled grid, the form of rounds 1-5)
+static bool dec_phases_deep() { static const bool on = [] { const char* s = getenv("CANONSWAP_DEC_PHASES_DEEP"); return !s || atoi(s) != 0; }(); return on; }
+
 int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, const float* kp_s, float* mask_out, hipStream_t st,
                      const float* warp_in = nullptr, float* warp_o32 = nullptr, half_t* warp_o16 = nullptr, bool want_deform = false,
                      bool shared_feat = false, bool shared_kps = false)
@@ -585,7 +588,11 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
         ConvCall c = mk(e->w_dec[i], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, S, S, 1);
         c.p.act0 = ACT_RELU;
         c.p.out0 = dhwc(e->dm_l[lv - 1], FD, S, S, lw[lv - 1]);
-        if (i >= 3) {
+        // Round 6: also up-blocks 0, 1 and 2 (1024 -> 512 from the 4 x 4 grid, 1024 -> 256 from the 8 x 8 one, 512 -> 128 from the 16 x 16 one) in
+        // the batched mode - on 128x128 tiles (4x4x8 / 8x8x2 positions, static shapes 17 / 13): 12 of 27 taps, 0.66 -> 0.32 ms per 64-frame launch
+        // for up-block 2.  In latency mode these three keep the 27-tap form: their launches are 8 - 64 workgroups there and run split-K, which a
+        // grouped launch does not.
+        if (i >= 3 || (!e->latency_mode && dec_phases_deep())) {
             // the nearest (1,2,2) up-sampling makes the three row / column taps read two source rows / columns: one 3x2x2 conv per
             // output phase (y, x) = (2i + a, 2j + b) on the source grid, 12 of 27 taps (pack.upsampled_conv3d_phases)
             // The four phases differ in their weights, their leading padding and their offset into the output only: ONE launch, blockIdx.z =
@@ -597,7 +604,7 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
             if (!grouped) {
                 for (int ab = 0; ab < 4; ++ab) {
                     const int a = ab >> 1, b = ab & 1;
-                    ConvCall q1 = mk(e->w_dec_p[i - 3][ab], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
+                    ConvCall q1 = mk(e->w_dec_p[i][ab], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
                     q1.p.PH = a == 0; q1.p.PW = b == 0;
                     q1.p.act0 = ACT_RELU;
                     q1.p.out0 = td(e->dm_l[lv - 1] + ((long)a * S + b) * lwo, (long)FD * S * S * lwo, (long)S * S * lwo, 2L * S * lwo, 2L * lwo);
@@ -606,18 +613,19 @@ int run_dense_motion(cs_engine* e, int B, const float* feat, const float* kp_d, 
                 }
                 continue;
             }
-            ConvCall q = mk(e->w_dec_p[i - 3][0], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
+            ConvCall q = mk(e->w_dec_p[i][0], e->dm_l[lv], dhwc(nullptr, FD, Si, Si, lw[lv]), B, FD, Si, Si);
             q.p.act0 = ACT_RELU;
             q.p.out0 = td(e->dm_l[lv - 1], (long)FD * S * S * lwo, (long)S * S * lwo, 2L * S * lwo, 2L * lwo);
             q.p.nphase = 4;
             for (int ab = 0; ab < 4; ++ab) {
                 const int a = ab >> 1, b = ab & 1;
-                q.p.ph_wofs[ab] = (long)(((intptr_t)e->w_dec_p[i - 3][ab].w - (intptr_t)e->w_dec_p[i - 3][0].w) / (intptr_t)sizeof(half_t));
+                q.p.ph_wofs[ab] = (long)(((intptr_t)e->w_dec_p[i][ab].w - (intptr_t)e->w_dec_p[i][0].w) / (intptr_t)sizeof(half_t));
                 q.p.ph_ooff[ab] = (unsigned)(((long)a * S + b) * lwo);
                 q.p.ph_PH[ab] = a == 0; q.p.ph_PW[ab] = b == 0;
             }
             q.p.PH = 1; q.p.PW = 1;
-            q.name = i == 3 ? "W.dec3.p" : "W.dec4.p";
+            static const char* const pn[5] = {"W.dec0.p", "W.dec1.p", "W.dec2.p", "W.dec3.p", "W.dec4.p"};
+            q.name = pn[i];
             if (i == 4) { q.hcfg = CFG_H_256x32; TRY(go(e, q, st, 4, 4)); }     // 32 output channels: 256-position tile
             else TRY(go(e, q, st));
             continue;
@@ -1249,10 +1257,10 @@ extern "C" int cs_finalize_weights(cs_engine* e)
     for (int i = 0; i < 5; ++i) {
         snprintf(n, sizeof n, "W.enc%d", i); TRY(get_conv(e, n, eci[i], eco[i], eco[i], 3, 3, 3, eco[i], (double)ecr[i] * eco[i] * 27, &e->w_enc[i]));
         snprintf(n, sizeof n, "W.dec%d", i); TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 3, 3, dco[i], (double)dci[i] * dco[i] * 27, &e->w_dec[i]));
-        for (int ab = 0; i >= 3 && ab < 4; ++ab) {      // algorithmic MACs per (source) position stay those of the 3x3x3 conv
+        for (int ab = 0; ab < 4; ++ab) {      // algorithmic MACs per (source) position stay those of the 3x3x3 conv
             snprintf(n, sizeof n, "W.dec%d.p%d%d", i, ab >> 1, ab & 1);
-            TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 2, 2, 0, (double)dci[i] * dco[i] * 27, &e->w_dec_p[i - 3][ab]));
-            e->w_dec_p[i - 3][ab].b = e->w_dec[i].b;
+            TRY(get_conv(e, n, dci[i], dco[i], dco[i], 3, 2, 2, 0, (double)dci[i] * dco[i] * 27, &e->w_dec_p[i][ab]));
+            e->w_dec_p[i][ab].b = e->w_dec[i].b;
         }
     }
     TRY(get_conv(e, "W.tail", 144, 160, 144, 3, 3, 3, 144, 142.0 * 142 * 27, &e->w_tail));

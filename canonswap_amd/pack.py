@@ -142,7 +142,7 @@ def _pack_W(out, sd):
             w, b = fold_conv_bn(sd[q + ".conv.weight"], sd[q + ".conv.bias"], s, t)
             out[f"W.{kind}{i}.w"] = pack_conv(w, w.shape[0])
             out[f"W.{kind}{i}.b"] = _f32(b)
-            if kind == "dec" and i >= 3:     # the two large up-blocks run per output phase on the source grid (engine.hip)
+            if kind == "dec":                # the up-blocks run per output phase on the source grid (engine.hip)
                 for (a, bb), (_, _, wab) in upsampled_conv3d_phases(w).items():
                     out[f"W.dec{i}.p{a}{bb}.w"] = pack_conv(wab, wab.shape[0])
     q = p + ".hourglass.decoder"
