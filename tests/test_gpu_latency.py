@@ -118,11 +118,13 @@ def test_latency_mode_worst_pool_frames(state_dicts, pool_modes, frame):
     assert pl >= ps - 0.5, (frame, pl, ps)            # the mode costs no margin: within half a dB of the default mode's value on the same frame
 
 
-@pytest.mark.parametrize("knob,lat", [("CANONSWAP_VOL32_XF=0", 0), ("CANONSWAP_WIDE=2", 0), ("CANONSWAP_WIDE=0", 0)])
+@pytest.mark.parametrize("knob,lat", [("CANONSWAP_VOL32_XF=0", 0), ("CANONSWAP_WIDE=2", 0), ("CANONSWAP_WIDE=0", 0),
+                                      ("CANONSWAP_SHARED_DEDUP=0", 0), ("CANONSWAP_DEC_PHASES_DEEP=0", 0)])
 def test_knob_product_paths_through_swap_frames(state_dicts, knob, lat, tmp_path):
     """The knobs that select another PRODUCT path (R's GroupNorm apply as its own launch instead of inside the consumer conv's staging; SPADE
     gamma / beta on conv_wide: the same bits) and the one that takes conv_wide out, through swap_frames in a process of their own, on pool frames
-    0 and 63.  (CANONSWAP_R_SPLIT=0 - R without its split-precision passes - measured 49.5 dB on frame 63 here and was removed: round 6.)"""
+    0 and 63; mlp_shared with every row phase launched (the same bits as the de-duplicated form) and the hourglass' up-blocks 0 - 2 as 27-tap convs.
+    (CANONSWAP_R_SPLIT=0 - R without its split-precision passes - measured 49.5 dB on frame 63 here and was removed: round 6.)"""
     import os
     import subprocess
     import sys
@@ -146,5 +148,5 @@ def test_knob_product_paths_through_swap_frames(state_dicts, knob, lat, tmp_path
         p = O.psnr(outs["knob"][j], ref)
         print(f"{knob} latency={lat} pool frame {j}: {p:.2f} dB (default build {O.psnr(outs['base'][j], ref):.2f})")
         assert p >= 50.0, (knob, j, p)
-        if k == "CANONSWAP_WIDE" and not lat:
+        if k in ("CANONSWAP_WIDE", "CANONSWAP_SHARED_DEDUP") and not lat:
             assert torch.equal(outs["knob"][j], outs["base"][j]), (knob, j)       # conv_wide and conv_halo add in the same order
