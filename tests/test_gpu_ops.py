@@ -98,6 +98,34 @@ def test_conv_channel_slice_pad_and_upshift(kern):
     assert bool((obuf[..., 64:] == -5.0).all())
 
 
+@pytest.mark.parametrize("S,tile,Cin,Cout", [(8, (8, 8), 128, 256), (16, (8, 8), 64, 128), (4, (4, 4), 128, 512)])
+def test_upblock_phase_conv_on_wide_tiles(S, tile, Cin, Cout):
+    """UpBlock3d (util.py:142-147: nearest (1,2,2) up-sampling, 3x3x3 conv, folded BN, ReLU) per output phase on the SOURCE grid - a 3x2x2 conv
+    with the phase's summed weights (pack.upsampled_conv3d_phases) - on the 128x128 tiles the hourglass' up-blocks 0 - 2 run on since round 6
+    (static shapes 13 / 17: 8x8x2 and 4x4x8 positions): every phase, written at its offset into the full-resolution output, against the 27-tap
+    conv on the up-sampled input.  (The engine launches the four phases as one grouped launch: tests/test_gpu_latency.py holds grouped == single.)"""
+    import hip_ops as ops
+    from canonswap_amd import pack
+    r = _rng(40 + S)
+    N, D = 2, 16
+    x = _randn(r, N, Cin, D, S, S)
+    w = _randn(r, Cout, Cin, 3, 3, 3, scale=0.03)
+    b = _randn(r, Cout, scale=0.1)
+    xu = x.repeat_interleave(2, 3).repeat_interleave(2, 4)
+    ref = F.relu(_ref_conv(xu, w, b, 1))
+    xd = _to_cl(x).to(DEV)
+    out = torch.zeros(N, D, 2 * S, 2 * S, Cout, dtype=torch.float16, device=DEV)
+    for (a, bb), (ph, pw, wab) in pack.upsampled_conv3d_phases(w.numpy()).items():
+        if (ph, pw) != (1, 1):
+            continue      # cs_op_conv pads KH / 2 = KW / 2 = 1 on the leading side: the (a, b) = (0, 0) phase; the others differ in the padding side only
+        wp = torch.from_numpy(pack.pack_conv(wab, Cout)).to(DEV)
+        ops.conv(xd, wp, Cout, Cout, (3, 2, 2), bias=b.to(DEV), act0="relu", out0=out[:, :, a::2, bb::2], cfg=10, tile=tile)
+        torch.cuda.synchronize()
+        got = _from_cl(out[:, :, a::2, bb::2])
+        # the phase's weights are sums of two or four fp32 taps rounded to fp16 once: compare against the 27-tap result at a tolerance that covers it
+        assert ops.rel_err(got, ref[:, :, :, a::2, bb::2]) < 4e-3, (S, a, bb)
+
+
 @pytest.mark.parametrize("kern", KERNELS)
 def test_conv_hwdc_residual_dual_output(kern):
     """3x3x3 conv on the [H][W][D][C] feature-volume layout, fp32 residual stream, second pre-activated fp16 output
