@@ -1043,6 +1043,86 @@ __global__ void __launch_bounds__(256, 4) t_mask_kernel(const half_t* __restrict
     }
 }
 
+// The same layer with vertical reuse for launches of many frames: a wave owns RH output rows of a SEG-column segment and marches over the columns
+// of its RH + 2 input rows, so a fetched 16 bytes feed up to nine dot products instead of three and the read out of the L2 per output drops from
+// 3 x 18 / 16 = 3.4 KiB to (RH + 2) / RH x (SEG + 2) / SEG = 1.9 KiB (RH = 4, SEG = 8): t_mask_kernel runs at the L2's rate (10.5 TB/s of reads at
+// 64 frames; more columns in flight made it slower, profiles/r06_v_dec_phases.txt).  Per output the same dot products in the same order as in
+// t_mask_kernel (column by column, kh ascending within a column; the lanes' partial sums reduced the same way): the same bits, so that the
+// launcher may choose by launch size (tests/test_gpu_ops.py).
+template <int SEG, int RH>
+__global__ void __launch_bounds__(256, 2) t_mask_rows_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wp, const float* __restrict__ bias,
+                                                             float* __restrict__ tmask, int N, int H, int W)
+{
+    constexpr int RS = 65;
+    __shared__ float part[4][RH][SEG * RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = W / SEG, nhb = H / RH;
+    long blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) blk = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long item = blk * 4 + wave;
+    const int sg = (int)(item % nseg); long r = item / nseg;
+    const int h0 = (int)(r % nhb) * RH;
+    const int n = (int)(r / nhb);
+    const int w0 = sg * SEG;
+    uint4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *(const uint4*)(wp + ((long)((lane >> 2) * 9 + t) * 16) * 32 + (lane & 3) * 8);
+    const half_t* xb = x + (long)n * H * W * 512 + lane * 8;
+    long roff[RH + 2]; bool rok[RH + 2];
+#pragma unroll
+    for (int i = 0; i < RH + 2; ++i) {
+        const int row = h0 - 1 + i;
+        rok[i] = (unsigned)row < (unsigned)H;
+        roff[i] = (long)(rok[i] ? row : h0) * W;
+    }
+    auto fetch = [&](int c, uint4 (&v)[RH + 2]) {          // input column w0 - 1 + c of the RH + 2 rows (zero outside the map)
+        const int wi = w0 - 1 + c;
+        const bool cin = (unsigned)wi < (unsigned)W;
+        const int wq = cin ? wi : w0;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < RH + 2; ++i) v[i] = *(const uint4*)(xb + (roff[i] + wq) * 512);
+#pragma unroll
+        for (int i = 0; i < RH + 2; ++i) if (!cin || !rok[i]) v[i] = z;
+    };
+    float a0[RH], a1[RH], a2[RH];
+#pragma unroll
+    for (int j = 0; j < RH; ++j) { a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; }
+    uint4 cur[RH + 2], nxt[RH + 2];
+    fetch(0, cur);
+#pragma unroll 2
+    for (int c = 0; c < SEG + 2; ++c) {
+        if (c + 1 < SEG + 2) fetch(c + 1, nxt);
+#pragma unroll
+        for (int j = 0; j < RH; ++j) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                a2[j] = tm_dot8(cur[j + kh], wt[kh * 3 + 0], a2[j]);
+                a1[j] = tm_dot8(cur[j + kh], wt[kh * 3 + 1], a1[j]);
+                a0[j] = tm_dot8(cur[j + kh], wt[kh * 3 + 2], a0[j]);
+            }
+            if (c >= 2) part[wave][j][(c - 2) * RS + lane] = a0[j];
+            a0[j] = a1[j]; a1[j] = a2[j]; a2[j] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RH + 2; ++k) cur[k] = nxt[k];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the wave's own LDS writes (no other wave reads them)
+    const int o = lane >> 2, q = lane & 3;
+#pragma unroll
+    for (int j = 0; j < RH; ++j) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += part[wave][j][(o < SEG ? o : 0) * RS + q * 16 + i];
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        if (q == 0 && o < SEG) {
+            const float y = sum + bias[0];
+            tmask[(((long)n * H + h0 + j) * W + w0 + o) * 4] = 1.f / (1.f + __expf(-y));
+        }
+    }
+}
+
 int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, float* tmask, int N, int H, int W, hipStream_t st)
 {
     // (a row-marching variant - a wave owns 8 output rows of a 16-column segment, every fetched 16 bytes feed nine dot products: 86 -> 75 us per
@@ -1051,6 +1131,14 @@ int launch_t_mask(const half_t* x, const half_t* wpacked, const float* bias, flo
     const long items = (long)N * H * (W / 16);
     if (items % 4 != 0) { cs_set_error("t_mask: N * H * W / 16 must be a multiple of 4"); return -1; }
     // (the segment length may depend on N: it does not change a bit of the result, tests/test_gpu_ops.py)
+    // from four frames of a 64 x 64 map up: 4 output rows x 8 columns per wave (the same bits; 76 -> 58 us per 64-frame launch, and faster at
+    // 4, 8, 16 and 32 frames too: profiles/r06_x_t_mask_rows.txt)
+    const long ritems = (long)N * (H / 4) * (W / 8);
+    if (items >= 1024 && H % 4 == 0 && W % 8 == 0 && ritems % 4 == 0) {
+        hipLaunchKernelGGL((t_mask_rows_kernel<8, 4>), dim3((unsigned)(ritems / 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
+        LAUNCH_CHECK("t_mask_rows");
+        return 0;
+    }
     if (items < 1024) hipLaunchKernelGGL(t_mask_kernel<4>, dim3((unsigned)items), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
     else hipLaunchKernelGGL(t_mask_kernel<16>, dim3((unsigned)cdiv(items, 4)), dim3(256), 0, st, x, wpacked, bias, tmask, N, H, W);
     LAUNCH_CHECK("t_mask");
